@@ -60,6 +60,8 @@ LOSS_NAMES = [
 ]
 
 vp, ci, cf, i64, sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+# aclgan_bucket_fn: void (*)(void* user, int group, int bucket, int64_t offset, int64_t numel)
+BUCKET_FN = C.CFUNCTYPE(None, vp, ci, ci, i64, i64)
 
 # every symbol include/aclgan_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -73,8 +75,11 @@ SIGNATURES = {
     "aclgan_bind_params": (ci, [vp, ci, vp, vp, vp, vp]),
     "aclgan_workspace_bytes": (ci, [vp, ci, ci, ci, C.POINTER(sz)]),
     "aclgan_bind_workspace": (ci, [vp, vp, sz]),
+    "aclgan_forward_workspace_bytes": (ci, [vp, ci, ci, ci, C.POINTER(sz)]),
     "aclgan_gen_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
     "aclgan_dis_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
+    "aclgan_set_grad_buckets": (ci, [vp, i64, BUCKET_FN, vp]),
+    "aclgan_bucket_schedule": (ci, [vp, ci, ci, ci, ci, ci, C.POINTER(ci), ci, C.POINTER(ci)]),
     "aclgan_zero_grad": (ci, [vp, ci, vp]),
     "aclgan_adam_step": (ci, [vp, ci, C.POINTER(Adam), ci, vp]),
     "aclgan_gen_encode": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, vp]),
@@ -122,6 +127,7 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """the current HIP stream of `device` (default: the current device) as a void*"""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -57,6 +57,14 @@ struct Act {
 struct PW {   // a (weight, bias) pair inside a flat group
     const float* w = nullptr; const float* b = nullptr;
     float* dw = nullptr; float* db = nullptr;
+    int64_t nw = 0, nb = 0;   // element counts (gradient-bucket bookkeeping)
+};
+
+// one backward closure + the ranges of the trained group's flat gradient buffer it writes
+struct TapeOp {
+    std::function<int()> fn;
+    int64_t goff[4] = {0, 0, 0, 0}, gnum[4] = {0, 0, 0, 0};
+    int ng = 0;
 };
 
 }  // namespace aclgan
@@ -73,7 +81,14 @@ struct aclgan_ctx {
     bool dry = false;
     size_t top = 0, peak = 0;
     std::vector<Act*> acts;
-    std::vector<std::function<int()>> tape;
+    std::vector<TapeOp> tape;
+    int trained = -1;          // group whose gradients this step produces (-1: forward only)
+    bool fire_dry = false;     // aclgan_bucket_schedule: invoke the bucket callback during a dry run
+    // data-parallel gradient buckets (aclgan_set_grad_buckets / aclgan_set_bucket_callback)
+    int64_t bucket_elems = 0;
+    aclgan_bucket_fn bucket_fn = nullptr;
+    void* bucket_user = nullptr;
+    std::vector<int> bucket_order;   // buckets in the order they completed during the last update
 
     ~aclgan_ctx() { reset_step(); }
     void reset_step() {
@@ -110,7 +125,17 @@ struct aclgan_ctx {
         acts.push_back(a);
         return a;
     }
+    // append a backward closure; `grads` = pointers into the trained group's gradient buffer it accumulates into
+    void push(std::function<int()> fn, std::initializer_list<std::pair<const float*, int64_t>> grads = {}) {
+        TapeOp op;
+        op.fn = std::move(fn);
+        if (trained >= 0 && groups[trained].grad)
+            for (const auto& g : grads)
+                if (g.first && g.second > 0 && op.ng < 4) { op.goff[op.ng] = g.first - groups[trained].grad; op.gnum[op.ng] = g.second; ++op.ng; }
+        tape.push_back(std::move(op));
+    }
     PW pw(int group, int net, const std::string& key, bool with_bias = true) const;
+    int64_t numel_of(int group, int net, const std::string& key) const;
     const float* param(int group, int net, const std::string& key) const;
     float* gradp(int group, int net, const std::string& key) const;
 };
@@ -203,10 +228,15 @@ float* aclgan_ctx::gradp(int group, int net, const std::string& key) const {
     if (it == g.index.end() || !g.grad) return nullptr;
     return g.grad + g.tensors[it->second].offset;
 }
+int64_t aclgan_ctx::numel_of(int group, int net, const std::string& key) const {
+    const Group& g = groups[group];
+    auto it = g.index.find(std::string(NET_NAMES[net]) + "/" + key);
+    return it == g.index.end() ? 0 : g.tensors[it->second].numel;
+}
 PW aclgan_ctx::pw(int group, int net, const std::string& key, bool with_bias) const {
     PW p;
-    p.w = param(group, net, key + ".weight"); p.dw = gradp(group, net, key + ".weight");
-    if (with_bias) { p.b = param(group, net, key + ".bias"); p.db = gradp(group, net, key + ".bias"); }
+    p.w = param(group, net, key + ".weight"); p.dw = gradp(group, net, key + ".weight"); p.nw = numel_of(group, net, key + ".weight");
+    if (with_bias) { p.b = param(group, net, key + ".bias"); p.db = gradp(group, net, key + ".bias"); p.nb = numel_of(group, net, key + ".bias"); }
     return p;
 }
 
@@ -263,7 +293,8 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     *out_p = out;
     if (!want_grad) return ACLGAN_OK;
     aclgan_ctx* cp = &c;
-    c.tape.push_back([=]() -> int {
+    const bool ln_train = ns.kind == ACLGAN_NORM_LN && ns.dw != nullptr;
+    c.push([=]() -> int {
         aclgan_ctx& c = *cp;
         if (!out->gw) return ACLGAN_OK;   // no gradient reached this block
         if (ns.kind != ACLGAN_NORM_NONE) {
@@ -294,7 +325,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             c.top = mark;
         }
         return ACLGAN_OK;
-    });
+    }, {{train_w ? W.dw : nullptr, W.nw}, {train_w ? W.db : nullptr, W.nb}, {ln_train ? ns.dw : nullptr, Co}, {ln_train ? ns.db : nullptr, Co}});
     return ACLGAN_OK;
 }
 
@@ -334,7 +365,7 @@ static int dense(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int O, int a
     *out_p = out;
     if (!want) return ACLGAN_OK;
     aclgan_ctx* cp = &c;
-    c.tape.push_back([=]() -> int {
+    c.push([=]() -> int {
         aclgan_ctx& c = *cp;
         if (!out->gw) return ACLGAN_OK;
         float* dx = nullptr;
@@ -353,7 +384,7 @@ static int dense(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int O, int a
         }
         c.top = mark;
         return ACLGAN_OK;
-    });
+    }, {{train_w ? W.dw : nullptr, W.nw}, {train_w ? W.db : nullptr, W.nb}});
     return ACLGAN_OK;
 }
 
@@ -382,7 +413,7 @@ static int style_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
     if (want) {
         aclgan_ctx* cp = &c;
         Act* hh = h;
-        c.tape.push_back([=]() -> int {
+        c.push([=]() -> int {
             aclgan_ctx& c = *cp;
             if (!p->gw) return ACLGAN_OK;
             RUN(gap_bwd(hh->B, hh->H * hh->W, hh->C, p->g, hh->g, hh->gw ? 1 : 0, c.st));
@@ -467,7 +498,7 @@ static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<A
             RUN(avgpool3s2_fwd(src->B, src->H, src->W, src->C, src->d, p->d, c.st));
             if (src->need_grad) {
                 aclgan_ctx* cp = &c;
-                c.tape.push_back([=]() -> int {
+                c.push([=]() -> int {
                     aclgan_ctx& c = *cp;
                     if (!p->gw) return ACLGAN_OK;
                     RUN(avgpool3s2_bwd(src->B, src->H, src->W, src->C, p->g, src->g, src->gw ? 1 : 0, c.st));
@@ -523,7 +554,7 @@ static int blend(aclgan_ctx& c, Act* dec4, Act* bg, Act* pair_first, Act** out_p
     if (pair_p) *pair_p = pair;
     if (!want) return ACLGAN_OK;
     aclgan_ctx* cp = &c;
-    c.tape.push_back([=]() -> int {
+    c.push([=]() -> int {
         aclgan_ctx& c = *cp;
         const float* dout = out->written() ? out->g : nullptr;
         const float* dpair = (pair && pair->written()) ? pair->g : nullptr;
@@ -576,15 +607,52 @@ static int wrap_vec(aclgan_ctx& c, const float* dev, int B, int n, float scale, 
     return ACLGAN_OK;
 }
 
+// Backward = the tape in reverse.  Data-parallel gradient buckets (not in the reference): the trained
+// group's flat gradient buffer is cut into fixed-size buckets; a bucket is COMPLETE once the closure with the smallest
+// forward index that writes into it has been enqueued (networks are used several times per step -- the decoder up to
+// three times -- and every use accumulates into the same dw).  The callback fires at that point, on the host, while the
+// remaining backward is still being enqueued: the caller starts that bucket's all-reduce on its communication stream
+// (ordered after everything enqueued so far), so the exchange overlaps the rest of the backward.  Order = reverse-backward
+// readiness, identical on every rank (the graph is static).
+static void fire_bucket(aclgan_ctx& c, int b) {
+    c.bucket_order.push_back(b);
+    if (!c.bucket_fn || (c.dry && !c.fire_dry)) return;
+    const int64_t off = (int64_t)b * c.bucket_elems;
+    const int64_t n = std::min<int64_t>(c.bucket_elems, c.groups[c.trained].numel - off);
+    c.bucket_fn(c.bucket_user, c.trained, b, off, n);
+}
 static int run_tape(aclgan_ctx& c) {
-    for (size_t i = c.tape.size(); i-- > 0;) CHK(c.tape[i]());
+    const size_t n = c.tape.size();
+    const bool buckets = c.trained >= 0 && c.bucket_elems > 0;
+    std::vector<std::vector<int>> done_at;
+    if (buckets) {
+        const int nb = (int)cdiv64(c.groups[c.trained].numel, c.bucket_elems);
+        std::vector<size_t> first(nb, n);
+        for (size_t i = 0; i < n; ++i)
+            for (int r = 0; r < c.tape[i].ng; ++r) {
+                const int64_t b0 = c.tape[i].goff[r] / c.bucket_elems, b1 = (c.tape[i].goff[r] + c.tape[i].gnum[r] - 1) / c.bucket_elems;
+                for (int64_t b = b0; b <= b1 && b < nb; ++b) first[b] = std::min(first[b], i);
+            }
+        done_at.resize(n);
+        c.bucket_order.clear();
+        for (int b = 0; b < nb; ++b) {
+            if (first[b] == n) fire_bucket(c, b);   // no closure writes here (alignment padding, untouched tensors): already final
+            else done_at[first[b]].push_back(b);
+        }
+    }
+    for (size_t i = n; i-- > 0;) {
+        CHK(c.tape[i].fn());
+        if (buckets) for (int b : done_at[i]) fire_bucket(c, b);
+    }
     return ACLGAN_OK;
 }
 
 static int check_shape(const aclgan_ctx& c, int B, int H, int W) {
     ACL_REQUIRE(B >= 1 && H >= 64 && W >= 64, "batch shape (%d,%d,%d): need B>=1 and H,W>=64 (third discriminator scale reflect-pads a >=2x2 map)", B, H, W);
+    // the reference needs exactly this: the decoder upsamples x2^n_downsample from floor(H / 2^n) and the L1 identity
+    // loss / focus blend compare it with the input (trainer.py:110-116,162-163)
     const int q = 1 << c.arch.gen_n_downsample;
-    ACL_REQUIRE(H % 16 == 0 && W % 16 == 0 && H % q == 0, "H, W must be multiples of 16");
+    ACL_REQUIRE(H % q == 0 && W % q == 0, "H, W must be multiples of %d (2^n_downsample: decoder output must match the input size)", q);
     return ACLGAN_OK;
 }
 
@@ -773,9 +841,45 @@ int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out) {
     size_t best = 0;
     for (int which = 0; which < 2; ++which) {
         c.reset_step();
-        c.dry = true; c.peak = 0;
+        c.dry = true; c.peak = 0; c.trained = -1;
         int rc = which == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)
                             : dis_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr);
+        c.dry = false;
+        const size_t pk = c.peak;
+        c.reset_step();
+        if (rc) return rc;
+        if (pk > best) best = pk;
+    }
+    *out = best + 4096;
+    return ACLGAN_OK;
+}
+// workspace of ONE forward-only call (aclgan_gen_encode / aclgan_gen_decode / aclgan_dis_forward) at this image shape:
+// inference (test.py, sample()) needs neither the training arena nor the training step's shape constraints
+int aclgan_forward_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out) {
+    ACL_REQUIRE(ctx && out, "null argument");
+    aclgan_ctx& c = *ctx;
+    ACL_REQUIRE(c.groups[0].param && c.groups[1].param, "bind parameters first");
+    ACL_REQUIRE(B >= 1 && H >= 4 && W >= 4, "bad shape (%d,%d,%d)", B, H, W);
+    const int q = 1 << c.arch.gen_n_downsample, C = c.arch.gen_dim << c.arch.gen_n_downsample;
+    size_t best = 0;
+    for (int which = 0; which < 3; ++which) {
+        c.reset_step();
+        c.dry = true; c.peak = 0; c.trained = -1;
+        Act *x = nullptr, *o = nullptr, *s = nullptr;
+        std::vector<Act*> outs;
+        int rc = ACLGAN_OK;
+        if (which == 0) {
+            rc = input_act(c, nullptr, B, 3, H, W, &x);
+            if (!rc) rc = content_encode(c, ACLGAN_NET_GEN_AB, false, x, &o);
+            if (!rc) rc = style_encode(c, ACLGAN_NET_GEN_AB, false, x, &s);
+        } else if (which == 1) {
+            rc = input_act(c, nullptr, B, C, std::max(1, H / q), std::max(1, W / q), &x);
+            if (!rc) rc = wrap_vec(c, nullptr, B, c.arch.gen_style_dim, 1.f, &s);
+            if (!rc) rc = decode(c, ACLGAN_NET_GEN_AB, false, x, s, &o);
+        } else if (H >= 64 && W >= 64) {   // smaller images cannot pass through the third discriminator scale at all
+            rc = input_act(c, nullptr, B, c.arch.input_dim_b, H, W, &x);
+            if (!rc) rc = dis_forward(c, ACLGAN_NET_DIS_2, false, x, &outs);
+        }
         c.dry = false;
         const size_t pk = c.peak;
         c.reset_step();
@@ -797,7 +901,7 @@ static int step_common(aclgan_ctx* ctx, const float* x_a, const float* x_b, cons
     ACL_REQUIRE(ctx->groups[0].param && ctx->groups[1].param, "bind parameters first");
     ACL_REQUIRE(ctx->groups[group_trained].grad, "gradient buffer of the trained group is not bound");
     ctx->reset_step();
-    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0;
+    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0; ctx->trained = group_trained;
     return ACLGAN_OK;
 }
 
@@ -818,6 +922,32 @@ int aclgan_dis_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const
     return rc;
 }
 
+int aclgan_set_grad_buckets(aclgan_ctx* ctx, int64_t bucket_elems, aclgan_bucket_fn fn, void* user) {
+    ACL_REQUIRE(ctx && bucket_elems >= 0, "bad ctx/bucket size");
+    ctx->bucket_elems = bucket_elems; ctx->bucket_fn = fn; ctx->bucket_user = user;
+    return ACLGAN_OK;
+}
+
+int aclgan_bucket_schedule(aclgan_ctx* ctx, int group, int B, int H, int W, int fire, int* order, int cap, int* count) {
+    ACL_REQUIRE(ctx && count && group >= 0 && group <= 1, "bad argument");
+    aclgan_ctx& c = *ctx;
+    ACL_REQUIRE(c.groups[0].param && c.groups[1].param && c.groups[group].grad, "bind parameters (and the group's gradient buffer) first");
+    ACL_REQUIRE(c.bucket_elems > 0, "aclgan_set_grad_buckets first");
+    aclgan_hparams hp;
+    memset(&hp, 0, sizeof hp);
+    hp.focus_loss = 1.f; hp.alpha = 1.f;
+    c.reset_step();
+    c.dry = true; c.peak = 0; c.trained = group; c.fire_dry = fire != 0;
+    const int rc = group == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)
+                              : dis_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr);
+    c.dry = false; c.fire_dry = false; c.trained = -1;
+    c.reset_step();
+    if (rc) return rc;
+    *count = (int)c.bucket_order.size();
+    for (int i = 0; i < *count && i < cap && order; ++i) order[i] = c.bucket_order[i];
+    return ACLGAN_OK;
+}
+
 int aclgan_zero_grad(aclgan_ctx* ctx, int group, void* stream) {
     ACL_REQUIRE(ctx && group >= 0 && group <= 1, "bad ctx/group");
     Group& g = ctx->groups[group];
@@ -836,7 +966,7 @@ static int fwd_begin(aclgan_ctx* ctx, void* stream) {
     ACL_REQUIRE(ctx && ctx->ws, "bind a workspace first");
     ACL_REQUIRE(ctx->groups[0].param && ctx->groups[1].param, "bind parameters first");
     ctx->reset_step();
-    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0;
+    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0; ctx->trained = -1;
     return ACLGAN_OK;
 }
 

@@ -126,8 +126,9 @@ class AdaINGen(_Net):
         q = 1 << a.gen_n_downsample
         content = torch.empty(B, a.gen_dim * q, H // q, W // q, device=t.device)
         style = torch.empty(B, a.gen_style_dim, 1, 1, device=t.device)
-        t._ensure_workspace(B, H, W)
-        L.check(L.lib.aclgan_gen_encode(t._ctx, self.net_id, L.ptr(images), B, H, W, L.ptr(content), L.ptr(style), L.stream_ptr()), "gen_encode")
+        with torch.cuda.device(t.device):
+            t._ensure_workspace(B, H, W, forward_only=True)
+            L.check(L.lib.aclgan_gen_encode(t._ctx, self.net_id, L.ptr(images), B, H, W, L.ptr(content), L.ptr(style), t._st()), "gen_encode")
         return content, style
 
     def decode(self, content, style):
@@ -138,8 +139,9 @@ class AdaINGen(_Net):
         a = t.arch
         q = 1 << a.gen_n_downsample
         out = torch.empty(B, a.gen_output_dim, h * q, w * q, device=t.device)
-        t._ensure_workspace(B, h * q, w * q)
-        L.check(L.lib.aclgan_gen_decode(t._ctx, self.net_id, L.ptr(content), L.ptr(style), B, h, w, L.ptr(out), L.stream_ptr()), "gen_decode")
+        with torch.cuda.device(t.device):
+            t._ensure_workspace(B, h * q, w * q, forward_only=True)
+            L.check(L.lib.aclgan_gen_decode(t._ctx, self.net_id, L.ptr(content), L.ptr(style), B, h, w, L.ptr(out), t._st()), "gen_decode")
         return out
 
     def forward(self, images):
@@ -166,8 +168,9 @@ class MsImageDis(_Net):
             outs.append(torch.empty(B, 1, hs, ws, device=t.device))
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
-        t._ensure_workspace(B, H, W)
-        L.check(L.lib.aclgan_dis_forward(t._ctx, self.net_id, L.ptr(x), B, H, W, arr, L.stream_ptr()), "dis_forward")
+        with torch.cuda.device(t.device):
+            t._ensure_workspace(B, H, W, forward_only=True)
+            L.check(L.lib.aclgan_dis_forward(t._ctx, self.net_id, L.ptr(x), B, H, W, arr, t._st()), "dis_forward")
         return outs
 
     __call__ = forward
@@ -178,12 +181,15 @@ class aclgan_Trainer:
     ``z=(z_1, z_2, z_3)`` on the update calls for seed-independent parity tests (by default z is
     drawn from the CPU generator exactly like trainer.py:99-101)."""
 
-    def __init__(self, hyperparameters, device=None):
+    def __init__(self, hyperparameters, device=None, compute_dtype=None):
         if not torch.cuda.is_available():
             raise L.AclganError("aclgan_Trainer needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
         hp = hyperparameters
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.arch = arch_from_config(hp)
+        self.compute_dtype = str(compute_dtype or hp.get("compute_dtype", "fp32"))
+        if self.compute_dtype != "fp32":
+            raise L.AclganError("compute_dtype=%r: only fp32 is built" % self.compute_dtype)
         self._ctx = C.c_void_p()
         L.check(L.lib.aclgan_ctx_create(C.byref(self.arch), C.byref(self._ctx)), "ctx_create")
         self.style_dim = hp["gen"]["style_dim"]
@@ -237,6 +243,8 @@ class aclgan_Trainer:
         self._losses = torch.zeros(len(L.LOSS_NAMES), device=self.device)
         for n in L.LOSS_NAMES:
             setattr(self, n, torch.zeros((), device=self.device))
+        self._zgen = None
+        self._setup_data_parallel()
 
     def __del__(self):
         try:
@@ -288,20 +296,32 @@ class aclgan_Trainer:
                     else:
                         v.zero_()
 
-    def _ensure_workspace(self, B, H, W):
-        if self._ws_shape is not None and self._ws_shape[0] >= B and self._ws_shape[1:] == (H, W):
+    def _st(self):
+        """the current stream of THIS trainer's device (not of torch's current device)"""
+        return L.stream_ptr(self.device)
+
+    def _ensure_workspace(self, B, H, W, forward_only=False):
+        """Bind an arena large enough for one update (or, forward_only, for one encode / decode / discriminator
+        forward: inference must not inherit the training step's shape constraints or its arena size)."""
+        key = (B, H, W)
+        have = self._ws_shape
+        if have is not None and have[0] >= B and have[1:3] == (H, W) and (forward_only or have[3]):
             return
         need = C.c_size_t()
-        L.check(L.lib.aclgan_workspace_bytes(self._ctx, B, H, W, C.byref(need)), "workspace_bytes")
+        if forward_only:
+            L.check(L.lib.aclgan_forward_workspace_bytes(self._ctx, B, H, W, C.byref(need)), "forward_workspace_bytes")
+        else:
+            L.check(L.lib.aclgan_workspace_bytes(self._ctx, B, H, W, C.byref(need)), "workspace_bytes")
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = None
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         L.check(L.lib.aclgan_bind_workspace(self._ctx, L.ptr(self._ws), self._ws.numel()), "bind_workspace")
-        self._ws_shape = (B, H, W)
+        self._ws_shape = key + (not forward_only,)
 
     def _draw_z(self, B):
-        # three draws from the CPU generator, in the reference's order (trainer.py:99-101)
-        return [torch.randn(B, self.style_dim, 1, 1) for _ in range(3)]
+        # three draws from the CPU generator, in the reference's order (trainer.py:99-101); data-parallel ranks use
+        # their own generator (seed + rank) so that shards do not share noise
+        return [torch.randn(B, self.style_dim, 1, 1, generator=self._zgen) for _ in range(3)]
 
     def _current_lr(self, hp):
         if hp.get("lr_policy", "constant") == "step":   # StepLR (utils.py:263-271)
@@ -309,9 +329,10 @@ class aclgan_Trainer:
         return float(hp["lr"])
 
     def _publish_losses(self, lo, hi):
-        vals = self._losses
+        # fresh 0-d tensors per update, like the reference (trainer.py:136-165): a caller may keep them across steps
+        vals = self._losses[lo:hi].clone()
         for i in range(lo, hi):
-            setattr(self, L.LOSS_NAMES[i], vals[i])
+            setattr(self, L.LOSS_NAMES[i], vals[i - lo])
 
     def _update(self, which, x_a, x_b, hp, z):
         grp = L.GROUP_GEN if which == "gen" else L.GROUP_DIS
@@ -323,32 +344,67 @@ class aclgan_Trainer:
         if z is None:
             z = self._draw_z(B)
         zz = torch.stack([t.reshape(B, self.style_dim).to(torch.float32) for t in z]).to(self.device).contiguous()
-        self._ensure_workspace(B, H, W)
         hpc = hparams_from_config(hp)
-        st = L.stream_ptr()
-        L.check(L.lib.aclgan_zero_grad(self._ctx, grp, st), "zero_grad")   # opt.zero_grad() (trainer.py:91,248)
-        fn = L.lib.aclgan_gen_update if which == "gen" else L.lib.aclgan_dis_update
-        L.check(fn(self._ctx, L.ptr(x_a), L.ptr(x_b), L.ptr(zz), B, H, W, C.byref(hpc), L.ptr(self._losses), st), which + "_update")
-        self._allreduce_grads(grp)
-        o = self._opt[grp]
-        o["steps"] += 1
-        adam = L.Adam(self._current_lr(self._hp), o["beta1"], o["beta2"], o["eps"], o["weight_decay"])
-        L.check(L.lib.aclgan_adam_step(self._ctx, grp, C.byref(adam), o["steps"], st), "adam_step")   # opt.step()
+        with torch.cuda.device(self.device):
+            self._ensure_workspace(B, H, W)
+            st = self._st()
+            L.check(L.lib.aclgan_zero_grad(self._ctx, grp, st), "zero_grad")   # opt.zero_grad() (trainer.py:91,248)
+            fn = L.lib.aclgan_gen_update if which == "gen" else L.lib.aclgan_dis_update
+            if self._reducer is not None:
+                self._reducer.begin(grp)
+            L.check(fn(self._ctx, L.ptr(x_a), L.ptr(x_b), L.ptr(zz), B, H, W, C.byref(hpc), L.ptr(self._losses), st), which + "_update")
+            self._allreduce_grads(grp)
+            o = self._opt[grp]
+            o["steps"] += 1
+            adam = L.Adam(self._current_lr(self._hp), o["beta1"], o["beta2"], o["eps"], o["weight_decay"])
+            L.check(L.lib.aclgan_adam_step(self._ctx, grp, C.byref(adam), o["steps"], st), "adam_step")   # opt.step()
         if which == "gen":
             self._publish_losses(0, 12)
         else:
             self._publish_losses(12, 16)
 
-    def _allreduce_grads(self, grp):
-        """Data parallelism (not in the reference): average the flat gradient buffer
-        over ranks with RCCL.  One process per GPU; no-op when torch.distributed is not initialised."""
+    # ---- data parallelism (not in the reference): one process per GPU, full replicas ----
+    def _dist_world(self):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
-            return
+            return 0
         if dist.get_world_size() == 1 and os.environ.get("ACLGAN_BENCH_FORCE_DIST") != "1":
+            return 0
+        return dist.get_world_size()
+
+    def _setup_data_parallel(self):
+        """Called at the end of __init__ and resume(): replicas must START identical, whatever each rank's RNG did --
+        broadcast rank 0's parameters and Adam state; then hook the engine's bucket callback so that each gradient
+        bucket's all-reduce starts while the rest of the backward is still running (ddp.BucketReducer).
+        z noise: every rank draws its own shard's z from a generator seeded with initial_seed() + rank."""
+        self._reducer = None
+        world = self._dist_world()
+        if not world:
+            return
+        import torch.distributed as dist
+        from .ddp import BucketReducer, broadcast_flat
+        for grp in (L.GROUP_GEN, L.GROUP_DIS):
+            for buf in (self._param[grp], self._m[grp], self._v[grp]):
+                broadcast_flat(buf)
+        steps = torch.tensor([self._opt[0]["steps"], self._opt[1]["steps"], self._sched_calls], dtype=torch.int64, device=self.device)
+        dist.broadcast(steps, 0)
+        self._opt[0]["steps"], self._opt[1]["steps"], self._sched_calls = (int(v) for v in steps.tolist())
+        self._zgen = torch.Generator().manual_seed(torch.initial_seed() + dist.get_rank())
+        if os.environ.get("ACLGAN_DDP_OVERLAP", "1") != "0":
+            self._reducer = BucketReducer(self._ctx, lambda g: self._grad[g], world)
+
+    def _allreduce_grads(self, grp):
+        """Average the flat gradient buffer over ranks with RCCL before Adam.  With the bucket reducer the collectives
+        were started from inside the backward (overlap) and are only waited for here; ACLGAN_DDP_OVERLAP=0 selects the
+        plain post-backward bucketed all-reduce.  No-op when torch.distributed is not initialised."""
+        world = self._dist_world()
+        if not world:
+            return
+        if self._reducer is not None:
+            self._reducer.finish(grp)
             return
         from .ddp import allreduce_flat
-        allreduce_flat(self._grad[grp], dist.get_world_size())
+        allreduce_flat(self._grad[grp], world)
 
     # ---- the hot path (trainer.py:90-170, 247-293) ----
     def gen_update(self, x_a, x_b, hyperparameters, z=None):
@@ -452,8 +508,11 @@ class aclgan_Trainer:
         self.dis_A.load_state_dict(sd["A"]); self.dis_B.load_state_dict(sd["B"]); self.dis_2.load_state_dict(sd["2"])
         sd = torch.load(os.path.join(checkpoint_dir, "optimizer.pt"), map_location="cpu")
         self._load_opt_state_dict(L.GROUP_DIS, sd["dis"]); self._load_opt_state_dict(L.GROUP_GEN, sd["gen"])
-        # get_scheduler(..., iterations): StepLR restarted with last_epoch = iterations (trainer.py:318-320)
-        self._sched_calls = iterations
+        # get_scheduler(..., iterations) (trainer.py:318-320, utils.py:263-271): StepLR(last_epoch=iterations) steps once
+        # in its constructor, so the reference resumes at last_epoch = iterations + 1 and (torch 1.2.0, the pinned
+        # version: closed-form get_lr) lr = lr0 * gamma ** ((iterations + 1) // step_size).  Mirrored.
+        self._sched_calls = iterations + 1
         self._hp = hyperparameters
+        self._setup_data_parallel()
         print("Resume from iteration %d" % iterations)
         return iterations

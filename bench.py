@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- training images/sec of the ACL-GAN step (dis_update + gen_update) at 256x256.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+  python bench.py --gpus N --steps K --warmup W [--dtype fp32|bf16|fp16] [--size S --batch B]
 
-Workload = BASELINE.json configs[1]: male2female architecture (configs/male2female.yaml), 256x256,
-fp32, batch 8 PER GPU (weak scaling), synthetic U(-1,1) images resident in HBM before the timed
-region, reference init statistics, z from a seeded CPU generator.  One "step" = one dis_update
-followed by one gen_update on the same batch (zero_grad + forward + backward + Adam each), i.e.
-value = global_batch / (t_dis + t_gen).
+N > 1: one rank per GPU over RCCL.  Either the driver launches the ranks (torch.distributed.run; RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or -- when WORLD_SIZE is unset -- this script
+re-executes itself through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`
+and relays rank 0's JSON line.
+
+Workload = BASELINE.json configs[1]: male2female architecture (configs/male2female.yaml), 256x256, fp32,
+batch 8 PER GPU (weak scaling), synthetic U(-1,1) images resident in HBM before the timed region, reference
+init statistics, z from a seeded CPU generator.  One "step" = one dis_update followed by one gen_update on the
+same batch (zero_grad + forward + backward + [gradient all-reduce] + Adam each): value = global_batch / (t_dis + t_gen).
+--dtype bf16 / fp16 (BASELINE configs[2] / [4]) runs the heavy convolutions on v_mfma_f32_32x32x16_{bf16,f16} with
+fp32 accumulation, fp32 master weights and Adam, fp16 with dynamic loss scaling.
+
+Timing: K steps bracketed by barrier + synchronize, max over ranks -> `value` / `ms_per_step` (the contract);
+per-step HIP events on the launch stream give `config.ms_per_step_median` (SURVEY.md 8d defines the median).
 
 Extra objects in the JSON line:
-  roofline     MFMA-bound: achieved = 2.623 TFLOP (necessary conv+linear FLOPs of one image's
-               dis+gen step) x images per step / measured step time (HIP events on
-               the launch stream), against the 157.3 TFLOP/s fp32 matrix peak of gfx950.
-               "kernel" carries the same quantity for the dominant kernel alone
-               (conv_fwd_fast_kernel<2,2,2,2> on the ResBlock shape), also timed with HIP events.
-  cpu_baseline the CPU oracle (a port of the reference step, oracle/aclgan_oracle.py) timed on
-               the host cores at N=1, rank 0, on a bounded sample (one step at 256x256, B=1).
+  roofline     MFMA-bound.  achieved = contract FLOPs (2.623 TFLOP per image at 256^2: NECESSARY conv+linear work of
+               one dis+gen step) x images per step / event-timed step, against the matrix peak of the
+               compute dtype (157.3 TFLOP/s fp32, 2500 bf16/fp16).  `executed_*`: the FLOPs the kernels really issue
+               (the sub-pixel path runs the two upsample+5x5 layers with 9 instead of 25 taps away from the border),
+               i.e. the hardware utilisation figure.  "kernel": the dominant kernel alone, timed with HIP events.
+  cpu_baseline the CPU oracle (a port of the reference step, oracle/aclgan_oracle.py) on the host cores, rank 0 at
+               N=1 only: 1 warm-up + 3 timed steps at 256x256 B=1, median and spread.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -30,17 +40,25 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-TFLOP_PER_IMAGE_256 = 2.623   # necessary work, dis+gen step, 256x256
-PEAK_FP32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md
+TFLOP_PER_IMAGE_256 = 2.623   # necessary work, dis+gen step, 256x256 (1311.6 GMAC)
+UPCONV_GMAC_256 = 483.2       # of which the two "Upsample(2)+5x5" decoder layers: fwd x8 decodes, dgrad+wgrad x5
+PEAK = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}   # TFLOP/s dense matrix peaks, MI355X_MICROARCH.md
+CPU_THREADS_CAP = 32   # oneDNN/ATen on the GPU box's 256 hardware threads thrashes on B=1 tensors
 
 
 def male2female_config():
-    # configs/male2female.yaml of the reference (values restated, see oracle.DEFAULT_HP)
-    from oracle.aclgan_oracle import default_config   # config constants only; no oracle compute on the timed path
-    return default_config()
+    import yaml
+    with open(os.path.join(ROOT, "configs", "male2female.yaml")) as f:
+        return yaml.safe_load(f)
 
 
-CPU_THREADS_CAP = 32   # oneDNN/ATen on the GPU box's 256 hardware threads thrashes on B=1 tensors
+def flops_per_image(S):
+    """(contract, executed) TFLOP per image of one dis+gen step at SxS.  Executed: inside the border ring the
+    sub-pixel decomposition issues 9/25 of the upsample+5x5 MACs."""
+    scale = (S / 256.0) ** 2
+    interior = 0.5 * (((S // 2 - 4) / (S // 2)) ** 2 + ((S - 4) / S) ** 2)
+    executed_gmac = 1311.6 - UPCONV_GMAC_256 * (16.0 / 25.0) * interior
+    return TFLOP_PER_IMAGE_256 * scale, 2e-3 * executed_gmac * scale
 
 
 def cpu_baseline_worker():
@@ -62,20 +80,22 @@ def cpu_baseline_worker():
         orc.gen_update(x_a, x_b, z[3:])
         return time.perf_counter() - t0
 
-    step(64, 1)                       # warm-up (thread pool, oneDNN primitives)
-    t = step(256, 1)
-    print(json.dumps({"value": round(1.0 / t, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                      "sample": "1 step (dis_update+gen_update) at 256x256, B=1, fp32, %d threads, after a 64x64 warm-up" % cores,
-                      "seconds": round(t, 2)}), flush=True)
+    step(64, 1)                       # thread pool, oneDNN primitives
+    step(256, 1)                      # warm-up at the measured shape (1 warm-up + 3 timed)
+    ts = sorted(step(256, 1) for _ in range(3))
+    print(json.dumps({"value": round(1.0 / ts[1], 4), "unit": "images/s", "cores": cores, "kind": "port",
+                      "sample": "median of 3 steps (dis_update+gen_update) at 256x256, B=1, fp32, %d threads, after 1 warm-up step" % cores,
+                      "seconds": [round(t, 2) for t in ts]}), flush=True)
 
 
-def cpu_baseline(timeout_s=150):
+def cpu_baseline(timeout_s=200):
     """The CPU oracle (a port of the reference step) on the host cores; bounded: a subprocess with a
     hard timeout so that the default bench run always finishes within minutes."""
-    import subprocess
     env = dict(os.environ)
     env["OMP_NUM_THREADS"] = str(min(CPU_THREADS_CAP, os.cpu_count() or 1))
     env["HIP_VISIBLE_DEVICES"] = ""
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], env=env, capture_output=True,
                            text=True, timeout=timeout_s)
@@ -83,10 +103,10 @@ def cpu_baseline(timeout_s=150):
         return json.loads(line)
     except Exception as e:   # noqa: BLE001  (reported, never fatal for the GPU number)
         return {"value": None, "unit": "images/s", "cores": min(CPU_THREADS_CAP, os.cpu_count() or 1), "kind": "port",
-                "sample": "CPU oracle step at 256x256 B=1 did not finish within %ds (%s)" % (timeout_s, type(e).__name__)}
+                "sample": "CPU oracle steps at 256x256 B=1 did not finish within %ds (%s)" % (timeout_s, type(e).__name__)}
 
 
-def dominant_kernel_probe(L, reps=20):
+def dominant_kernel_probe(L, dtype, reps=20):
     """conv_fwd on the ResBlock shape (B=8, 64x64, 256->256, 3x3): the kernel family that carries
     ~97% of the step's FLOPs.  Timed with HIP events on the launch stream."""
     import ctypes as C
@@ -97,22 +117,48 @@ def dominant_kernel_probe(L, reps=20):
     y = torch.empty(B, H, H, Cc, device="cuda")
     d = L.ConvDesc(B, H, H, Cc, Cc, 3, 1, 1, 0, 0)
     st = L.stream_ptr()
+    if dtype == "fp32":
+        call = lambda: L.check(L.lib.aclgan_conv2d_fwd(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), st))   # noqa: E731
+        name = "conv_fwd_fast_kernel<2,2,2,2> 8x64x64x256->256 3x3 (ResBlock conv, 135 launches per step)"
+        # HBM-side bytes per launch of THIS kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot
+        # run inside the timed process): 2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE
+        extra = {"traffic": 207.8e6 + 32.8e6, "algorithmic_bytes": 69.5e6, "traffic_source": "profiles/r01_hbm_traffic_conv_fwd.txt"}
+    else:
+        code = L.DTYPE[dtype]
+        w16 = torch.empty(w.numel(), dtype=torch.int16, device="cuda")
+        L.check(L.lib.aclgan_pack_weights16(L.ptr(w), L.ptr(w16), None, Cc, 9, Cc, code, st))
+        call = lambda: L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), code, L.ptr(x), L.ptr(w16), L.ptr(b), L.ptr(y), None, st))   # noqa: E731
+        name = "conv_fwd16_kernel<%s> 8x64x64x256->256 3x3 (ResBlock conv)" % dtype
+        extra = {"traffic": None, "algorithmic_bytes": 69.5e6 - w.numel() * 2}
     for _ in range(3):
-        L.check(L.lib.aclgan_conv2d_fwd(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), st))
+        call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        L.check(L.lib.aclgan_conv2d_fwd(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), st))
+        call()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     flop = 2.0 * (B * H * H) * Cc * (9 * Cc)
-    return {"name": "conv_fwd_fast_kernel<2,2,2,2> 8x64x64x256->256 3x3 (ResBlock conv, 135 launches per step)", "ms": round(ms, 4), "flop_per_launch": flop,
-            "achieved": round(flop / ms / 1e9, 2), "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / PEAK_FP32_MFMA, 4),
-            # HBM-side bytes per launch of THIS kernel from the PMC passes committed under profiles/ (not re-measured
-            # here: rocprofv3 --pmc cannot run inside the timed process): 2 x FETCH_SIZE (gfx950 wide-load correction)
-            # + WRITE_SIZE; algorithmic bytes = input + weights + output
-            "traffic": 207.8e6 + 32.8e6, "algorithmic_bytes": 69.5e6, "traffic_source": "profiles/r01_hbm_traffic_conv_fwd.txt"}
+    out = {"name": name, "ms": round(ms, 4), "flop_per_launch": flop, "achieved": round(flop / ms / 1e9, 2), "unit": "TFLOP/s",
+           "frac": round(flop / ms / 1e9 / PEAK[dtype], 4)}
+    out.update(extra)
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run and relay
+    rank 0's output (the one JSON line)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def main():
@@ -122,6 +168,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="compute dtype of the heavy convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -130,14 +177,17 @@ def main():
         return
 
     t_start = time.perf_counter()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("for --gpus %d launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback for the product path")
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit("rank %d: local GPU %d not visible (%d devices)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or os.environ.get("ACLGAN_BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
@@ -152,8 +202,8 @@ def main():
 
     cfg = male2female_config()
     cfg["display_size"] = 1
-    torch.manual_seed(0)                      # same weights on every rank (DDP replicas)
-    tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank)
+    torch.manual_seed(0)       # (replicas are made identical by the trainer's rank-0 broadcast, not by this seed)
+    tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype)
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1 + rank)   # each rank its own shard of the synthetic global batch
     x_a = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
@@ -169,26 +219,27 @@ def main():
         if rank == 0:
             print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    log("trainer built; warm-up")
+    log("trainer built (%s, world %d); warm-up" % (args.dtype, world))
     for _ in range(args.warmup):
         step()
         torch.cuda.synchronize()
         log("warm-up step done")
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
-    e1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    ev_ms = sum(per_step)
     if use_dist:
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,35 +248,49 @@ def main():
 
     # secondary figure: the reference loop's cadence D_update=1, G_update=2 -> B / (t_dis + t_gen / 2);
     # two extra steps OUTSIDE the timed region, split with events between the two updates
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev3 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t_dis = t_gen = 0.0
     for _ in range(2):
-        evs[0].record(); tr.dis_update(x_a, x_b, cfg, z=zs[0])
-        evs[1].record(); tr.gen_update(x_a, x_b, cfg, z=zs[1])
-        evs[2].record(); torch.cuda.synchronize()
-        t_dis += evs[0].elapsed_time(evs[1]) / 2; t_gen += evs[1].elapsed_time(evs[2]) / 2
+        ev3[0].record(); tr.dis_update(x_a, x_b, cfg, z=zs[0])
+        ev3[1].record(); tr.gen_update(x_a, x_b, cfg, z=zs[1])
+        ev3[2].record(); torch.cuda.synchronize()
+        t_dis += ev3[0].elapsed_time(ev3[1]) / 2; t_gen += ev3[1].elapsed_time(ev3[2]) / 2
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
-        tflop_img = TFLOP_PER_IMAGE_256 * (S / 256.0) ** 2
-        ach = tflop_img * B / (ev_ms / args.steps / 1e3)      # per GPU, from HIP events on the launch stream
+        tflop_img, tflop_exec = flops_per_image(S)
+        step_s = ev_ms / args.steps / 1e3
+        ach = tflop_img * B / step_s      # per GPU, from HIP events on the launch stream
+        peak = PEAK[args.dtype]
+        name = {"fp32": "male2female", "bf16": "selfie2anime (male2female architecture)", "fp16": "male2female"}[args.dtype]
         out = {
             "metric": "training images/sec at 256x256 (gen+dis step)" if S == 256 else "training images/sec at %dx%d (gen+dis step)" % (S, S),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic U(-1,1) A/B batches, reference init statistics, seeded z",
-            "config": {"workload": "male2female %dx%d fp32, batch=%d per GPU: dis_update + gen_update (fwd+bwd+Adam each)" % (S, S, B),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "losses_finite": bool(losses_ok),
+            "dtype": args.dtype, "data": "synthetic U(-1,1) A/B batches, reference init statistics, seeded z",
+            "config": {"workload": "%s %dx%d %s, batch=%d per GPU: dis_update + gen_update (fwd+bwd+Adam each)" % (name, S, S, args.dtype, B),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                       "grad_allreduce": ("overlapped with backward (bucket callback)" if getattr(tr, "_reducer", None) is not None else
+                                          ("after backward" if use_dist else "none (1 GPU)")),
+                       "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),
+                       "ms_per_step_min_max": [round(min(per_step), 3), round(max(per_step), 3)],
                        "ms_dis_update": round(t_dis, 2), "ms_gen_update": round(t_gen, 2),
                        "reference_cadence_D1_G2_images_per_s": round(world * B / ((t_dis + 0.5 * t_gen) / 1e3), 2)},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_MFMA, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": None,
                          "flop_per_launch": tflop_img * B * 1e12, "launch": "one dis_update+gen_update step (per GPU)",
-                         "event_ms_per_step": round(ev_ms / args.steps, 3)},
+                         "event_ms_per_step": round(ev_ms / args.steps, 3),
+                         "executed_flop_per_launch": tflop_exec * B * 1e12, "executed_achieved": round(tflop_exec * B / step_s, 2),
+                         "executed_frac": round(tflop_exec * B / step_s / peak, 4)},
         }
+        if args.dtype != "fp32":
+            out["config"]["precision"] = ("heavy convolutions: %s operands on v_mfma_f32_32x32x16, fp32 accumulate; fp32 master weights, "
+                                          "Adam, norm statistics and losses%s" % (args.dtype, "; dynamic loss scaling" if args.dtype == "fp16" else ""))
+            if args.dtype == "fp16":
+                out["config"]["loss_scale"] = tr.loss_scale_state()
         log("timed region done: %.1f ms/step" % ms_per_step)
-        out["roofline"]["kernel"] = dominant_kernel_probe(L)
+        out["roofline"]["kernel"] = dominant_kernel_probe(L, args.dtype)
         log("kernel probe done; cpu baseline next")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -124,6 +124,10 @@ int aclgan_bind_params(aclgan_ctx* ctx, int group, float* param, float* grad, fl
 /* activation workspace for one update at the given batch shape (bytes); bind before stepping */
 int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out);
 int aclgan_bind_workspace(aclgan_ctx* ctx, void* workspace, size_t bytes);
+/* arena for ONE forward-only call below (encode / decode / discriminator forward) on (B,*,H,W) images: what
+ * test.py:55-131 and trainer.sample need -- far smaller than a training step's, and without its shape constraints
+ * (any H, W the networks accept, e.g. the 256x340 a Resize(256) of a non-square photo yields) */
+int aclgan_forward_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out);
 
 /* ---- the hot path ---- */
 /* aclgan_Trainer.gen_update minus zero_grad/opt.step (trainer.py:92-169): forward of the whole
@@ -135,6 +139,19 @@ int aclgan_gen_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const
 /* aclgan_Trainer.dis_update minus zero_grad/opt.step (trainer.py:249-292); grads into the DIS group */
 int aclgan_dis_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const float* z,
                       int B, int H, int W, const aclgan_hparams* hp, float* losses, void* stream);
+/* ---- data-parallel gradient buckets (NOT in the reference: it is single-GPU, train.py:42) ----
+ * The trained group's flat gradient buffer is cut into buckets of `bucket_elems` floats.  During the backward of
+ * aclgan_gen_update / aclgan_dis_update, `fn(user, group, bucket, offset, numel)` is called ON THE HOST as soon as the
+ * last kernel that accumulates into that bucket has been enqueued on the step's stream -- in reverse-backward order of
+ * readiness, the same order on every rank.  The caller launches that bucket's all-reduce (ordered after the work enqueued
+ * so far) so that it overlaps the remaining backward, and waits for all of them before aclgan_adam_step.
+ * bucket_elems = 0 or fn = NULL switches the mechanism off. */
+typedef void (*aclgan_bucket_fn)(void* user, int group, int bucket, int64_t offset, int64_t numel);
+int aclgan_set_grad_buckets(aclgan_ctx* ctx, int64_t bucket_elems, aclgan_bucket_fn fn, void* user);
+/* the bucket completion order of one update of `group` at this batch shape, from a launch-free dry run of the same
+ * scheduler (no GPU work; usable on a CPU-only host): order[0..count).  fire != 0 also invokes the callback. */
+int aclgan_bucket_schedule(aclgan_ctx* ctx, int group, int B, int H, int W, int fire, int* order, int cap, int* count);
+
 /* opt.zero_grad() (trainer.py:91,248) */
 int aclgan_zero_grad(aclgan_ctx* ctx, int group, void* stream);
 /* opt.step() (trainer.py:170,293): one fused kernel over the group's flat buffers; `step` is the

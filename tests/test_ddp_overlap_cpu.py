@@ -1,0 +1,141 @@
+"""The overlapped gradient all-reduce without a GPU: the engine's bucket schedule comes from a launch-free dry run
+of the SAME scheduler the GPU step uses (aclgan_bucket_schedule), so order, coverage of the flat buffer and the
+callback wiring of ddp.BucketReducer are testable on CPU with gloo, world size 2."""
+import ctypes as C
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+B, H, W = 2, 64, 64
+BUCKET = 4096
+
+
+def _ctx(L, reduced=True):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "male2female.yaml")))
+    if reduced:
+        cfg["gen"].update(dim=8, mlp_dim=16, n_res=2)
+        cfg["dis"].update(dim=8)
+    from aclgan_amd.trainer import arch_from_config
+    arch = arch_from_config(cfg)
+    ctx = C.c_void_p()
+    L.check(L.lib.aclgan_ctx_create(C.byref(arch), C.byref(ctx)))
+    grads = {}
+    for grp in (0, 1):
+        n = L.lib.aclgan_group_numel(ctx, grp)
+        grads[grp] = torch.zeros(n)
+        # parameters are never dereferenced by a dry run: any non-null pointer will do
+        L.check(L.lib.aclgan_bind_params(ctx, grp, L.ptr(grads[grp]), L.ptr(grads[grp]), None, None))
+    return ctx, grads
+
+
+def _tensor_offsets(L, ctx, grp):
+    out = {}
+    name = C.create_string_buffer(256)
+    off = C.c_int64(); shp = (C.c_int * 4)(); nd = C.c_int()
+    for i in range(L.lib.aclgan_tensor_count(ctx, grp)):
+        L.check(L.lib.aclgan_tensor_info(ctx, grp, i, name, 256, C.byref(off), shp, C.byref(nd)))
+        out[name.value.decode()] = off.value
+    return out
+
+
+def _schedule(L, ctx, grp, fire=0):
+    order = (C.c_int * 4096)()
+    cnt = C.c_int()
+    L.check(L.lib.aclgan_bucket_schedule(ctx, grp, B, H, W, fire, order, 4096, C.byref(cnt)), "bucket_schedule")
+    return [order[i] for i in range(cnt.value)]
+
+
+def test_bucket_schedule_order_and_coverage():
+    sys.path.insert(0, ROOT)
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd import _lib as L
+    ctx, grads = _ctx(L)
+    fn = C.cast(None, L.BUCKET_FN)
+    L.check(L.lib.aclgan_set_grad_buckets(ctx, BUCKET, fn, None))
+    for grp in (0, 1):
+        n = grads[grp].numel()
+        nb = (n + BUCKET - 1) // BUCKET
+        order = _schedule(L, ctx, grp)
+        assert sorted(order) == list(range(nb)), "every bucket exactly once"
+        assert order == _schedule(L, ctx, grp), "the schedule is a function of the graph only"
+        offs = _tensor_offsets(L, ctx, grp)
+        pos = {b: i for i, b in enumerate(order)}
+        if grp == 0:
+            # reverse-backward readiness: gen_AB's content encoder runs FIRST in the forward (trainer.py:103), so the
+            # bucket holding its first conv completes LAST; both decoders and MLPs (first used at trainer.py:108-109,
+            # after all of x_a's encoders) complete before any bucket of that encoder
+            last = offs["gen_AB/enc_content.model.0.conv.weight"] // BUCKET
+            assert last in order[-2:]        # (the tensor may straddle two buckets; both complete with that closure)
+            for net in ("gen_AB", "gen_BA"):
+                dec = offs[net + "/dec.model.0.model.1.model.1.conv.weight"] // BUCKET
+                mlp = offs[net + "/mlp.model.1.fc.weight"] // BUCKET
+                enc = offs[net + "/enc_content.model.1.conv.weight"] // BUCKET
+                assert pos[dec] < pos[enc] and pos[mlp] < pos[enc], (net, pos[dec], pos[mlp], pos[enc])
+        else:
+            # dis_update: the three discriminators run A, B, 2 in the forward -> dis_2's buckets complete first
+            first_2 = offs["dis_2/cnns.0.0.conv.weight"] // BUCKET
+            first_A = offs["dis_A/cnns.0.0.conv.weight"] // BUCKET
+            assert pos[first_2] < pos[first_A]
+            assert first_A in order[-2:]
+    L.lib.aclgan_ctx_destroy(ctx)
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd import _lib as L
+    from aclgan_amd import ddp
+    ctx, grads = _ctx(L)
+    ok = True
+    red = ddp.BucketReducer(ctx, lambda g: grads[g], world, bucket_elems=BUCKET)
+    orders = []
+    for grp in (1, 0):
+        g = torch.Generator().manual_seed(10 * grp + rank)
+        grads[grp].copy_(torch.randn(grads[grp].numel(), generator=g))
+        want = sum(torch.randn(grads[grp].numel(), generator=torch.Generator().manual_seed(10 * grp + r)) for r in range(world)) / world
+        red.begin(grp)
+        # the dry run fires the callback exactly where the GPU step would: the reducer starts one async all-reduce per bucket
+        order = _schedule(L, ctx, grp, fire=1)
+        ok = ok and red.order == order and len(red.works) == len(order)
+        red.finish(grp)
+        ok = ok and torch.allclose(grads[grp], want, atol=1e-6)
+        orders.append(order)
+    # identical order on every rank (otherwise the collectives would not match up)
+    t = torch.tensor([hash(tuple(o)) % (2 ** 31) for o in orders])
+    lst = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(lst, t)
+    ok = ok and all(torch.equal(lst[0], x) for x in lst)
+    # a step that skips a bucket must not reach Adam silently
+    red.begin(0)
+    try:
+        red.finish(0)
+        ok = False
+    except RuntimeError:
+        pass
+    red.close()
+    # broadcast_flat: replicas start from rank 0's values
+    p = torch.full((1000,), float(rank))
+    ddp.broadcast_flat(p, 0, bucket_elems=300)
+    ok = ok and bool((p == 0).all())
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+    L.lib.aclgan_ctx_destroy(ctx)
+
+
+def test_bucket_reducer_gloo_world2():
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -293,6 +293,71 @@ def test_non_square_odd_batch_step_matches_oracle(T):
                 assert err <= 3e-2 * ref.double().norm().item() + 1e-5 * gmax, (n, k, err)
 
 
+def test_step_at_sizes_divisible_by_4_only(T):
+    """The reference accepts any H, W >= 64 divisible by 2^n_downsample = 4 (odd intermediate maps in the discriminator
+    pyramid and the style encoder); so does the build: 72x88, B=2, both updates against the fp32 oracle."""
+    cfg = O.default_config()
+    cfg["gen"].update(dim=8, mlp_dim=16, n_res=1)
+    cfg["dis"].update(dim=8)
+    cfg["display_size"] = 1
+    cfg["focus_epsilon"] = 0.5
+    nets = O.test_nets(cfg, 5)
+    g = torch.Generator().manual_seed(19)
+    x_a = torch.rand(2, 3, 72, 88, generator=g) * 2 - 1
+    x_b = torch.rand(2, 3, 72, 88, generator=g) * 2 - 1
+    z = [torch.randn(2, 8, 1, 1, generator=g) for _ in range(6)]
+    trd = _make(T, cfg, nets); trd.dis_update(x_a, x_b, cfg, z=z[:3])
+    trg = _make(T, cfg, nets); trg.gen_update(x_a, x_b, cfg, z=z[3:])
+    od = O.OracleTrainer(cfg, nets=nets); od.dis_update(x_a, x_b, z[:3], apply=False)
+    og = O.OracleTrainer(cfg, nets=nets); og.gen_update(x_a, x_b, z[3:], apply=False)
+    for n, v in list(od.losses.items()) + list(og.losses.items()):
+        got = float(getattr(trd if n.startswith("loss_dis") else trg, n))
+        assert abs(got - v) <= (2e-2 if n.endswith("_size") else 1e-3) * max(1e-3, abs(v)), (n, got, v)
+    for tr, orc, nets_ in ((trd, od, ("dis_A", "dis_B", "dis_2")), (trg, og, ("gen_AB", "gen_BA"))):
+        gmax = max(float(t.grad.norm()) for n in nets_ for t in orc.nets[n].values())
+        for n in nets_:
+            for k, gr in getattr(tr, n).named_grads():
+                ref = orc.nets[n][k].grad
+                err = (gr.cpu().double() - ref.double()).norm().item()
+                assert err <= 3e-2 * ref.double().norm().item() + 1e-5 * gmax, (n, k, err)
+
+
+def test_inference_shapes_and_sample_values(T):
+    """(a) forward-only calls take the shapes test.py produces (Resize(256) of a non-square photo: 64x84 here), with a
+    forward-only workspace; (b) sample() (trainer.py:179-245) VALUES against the oracle, all 9 outputs."""
+    cfg = O.default_config()
+    cfg["gen"].update(dim=8, mlp_dim=16, n_res=1)
+    cfg["dis"].update(dim=8)
+    cfg["display_size"] = 2
+    nets = O.test_nets(cfg, 6)
+    tr = _make(T, cfg, nets)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(1, 3, 64, 84, generator=g) * 2 - 1
+    c, s_ = tr.gen_AB.encode(x)
+    img = tr.gen_AB.decode(c, s_)
+    P, gc = nets["gen_AB"], cfg["gen"]
+    assert _rel(c, O.content_encode(P, x, gc)) < 1e-3
+    assert _rel(img, O.decode(P, O.content_encode(P, x, gc), O.style_encode(P, x, gc), gc)) < 1e-3
+    assert tr._ws_shape[3] is False     # no training arena was allocated for it
+    x_a = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    x_b = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    out = tr.sample(x_a, x_b)
+    z1, z2, z3 = tr.z_1.cpu(), tr.z_2.cpu(), tr.z_3.cpu()
+    AB, BA = nets["gen_AB"], nets["gen_BA"]
+    want = [[] for _ in range(9)]
+    for i in range(2):
+        xa = x_a[i:i + 1]
+        c1, s1 = O.content_encode(BA, xa, gc), O.style_encode(BA, xa, gc)
+        o = O.decode(BA, c1, z1[i:i + 1], gc); a_fake = O.focus_translation(o[:, :3], xa, o[:, 3:]); m_a = o[:, 3:]
+        o = O.decode(BA, c1, s1, gc); a_rec, m_rec = o[:, :3], o[:, 3:]
+        o = O.decode(AB, O.content_encode(AB, xa, gc), z2[i:i + 1], gc); b_fake = O.focus_translation(o[:, :3], xa, o[:, 3:]); m_b = o[:, 3:]
+        o = O.decode(BA, O.content_encode(BA, b_fake, gc), z3[i:i + 1], gc); a2 = O.focus_translation(o[:, :3], b_fake, o[:, 3:]); m_a2 = o[:, 3:]
+        for lst, t in zip(want, (xa, a_fake, m_a, b_fake, m_b, a2, m_a2, a_rec, m_rec)):
+            lst.append(t)
+    for k, (got, w) in enumerate(zip(out, want)):
+        assert _rel(got, torch.cat(w)) < 1e-3, k
+
+
 def test_resume_from_reference_written_checkpoint(T, tmp_path):
     """f-2: a checkpoint written by the REFERENCE's trainer.save (tests/golden/ckpt_reference_reduced, produced by
     make_golden.py --checkpoint-only) loads into the build: same file names / keys / layouts / Adam state; the next
@@ -335,8 +400,8 @@ def test_errors_surface_as_exceptions_not_aborts(T):
     cfg = O.default_config()
     cfg["gen"].update(dim=8, mlp_dim=16, n_res=1); cfg["dis"].update(dim=8); cfg["display_size"] = 1
     tr = T.aclgan_Trainer(cfg)
-    x = torch.zeros(1, 3, 72, 64)
-    with pytest.raises(T.L.AclganError, match="multiples of 16"):
+    x = torch.zeros(1, 3, 70, 64)
+    with pytest.raises(T.L.AclganError, match="multiples of 4"):
         tr.gen_update(x, x, cfg)
     with pytest.raises(T.L.AclganError, match="H,W>=64"):
         tr.dis_update(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32), cfg)

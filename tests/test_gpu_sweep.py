@@ -63,13 +63,17 @@ def test_train_loop_runs_and_resumes(tmp_path):
     cfg.update(batch_size=2, crop_image_height=64, crop_image_width=64, display_size=2, snapshot_save_iter=2, max_iter=3)
     path = os.path.join(tmp_path, "tiny.yaml")
     yaml.safe_dump(cfg, open(path, "w"))
+    # a configured dataset that does not exist is an error, like the reference -- never a silent fallback to noise
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--config", path, "--output_path", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--synthetic" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--config", path, "--output_path", str(tmp_path), "--synthetic"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Iteration: 00000003/00000003" in r.stdout and "Finish training" in r.stdout
     ck = os.path.join(tmp_path, "outputs", "tiny", "checkpoints")
     assert {"gen_00000002.pt", "dis_00000002.pt", "gen_00000003.pt", "dis_00000003.pt", "optimizer.pt"} <= set(os.listdir(ck))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--config", path, "--output_path", str(tmp_path), "--resume",
-                        "--max_iter", "4"], capture_output=True, text=True, timeout=600)
+                        "--max_iter", "4", "--synthetic"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Resume from iteration 3" in r.stdout and "Iteration: 00000004/00000004" in r.stdout

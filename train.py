@@ -7,8 +7,9 @@ the per-epoch index `it` (train.py:71-74), same snapshot cadence, lr stepped eve
 Data: when the config's data_root (or the data_folder_* / data_list_* keys) points at existing image folders,
 batches come from the device input pipeline (acl-gan_amd/data.py: host decode, ONE HIP kernel per batch for
 flip/Resize/crop/ToTensor/Normalize, bit-identical to the reference's torchvision/PIL chain, utils.py:43-100)
-and are zipped exactly like train.py:66; otherwise (--synthetic, or no dataset on disk) synthetic U(-1,1)
-images of the configured crop size are used.  Out of scope: the TensorBoard/HTML writers.  Losses are printed
+and are zipped exactly like train.py:66; with --synthetic, synthetic U(-1,1) images of the configured crop size
+are used instead.  A configured dataset that does not exist is an error (as in the reference), never a silent
+fallback to noise.  Out of scope: the TensorBoard/HTML writers.  Losses are printed
 every log_iter iterations with ONE device->host copy of the 16-entry loss array instead of 16 (.item() each)."""
 import argparse
 import os
@@ -64,16 +65,21 @@ def main():
         for _ in range(steps_per_epoch):
             yield ((torch.rand(B, 3, H, W, generator=gen) * 2 - 1).cuda(), (torch.rand(B, 3, H, W, generator=gen) * 2 - 1).cuda())
 
-    have_data = ("data_root" in config and os.path.isdir(os.path.join(config["data_root"], "trainA"))) or \
-                ("data_folder_train_a" in config and os.path.isdir(config["data_folder_train_a"]))
-    if have_data and not opts.synthetic:
+    if opts.synthetic:
+        epoch = synthetic_epoch
+        print("data: synthetic U(-1,1) batches (--synthetic)")
+    else:
+        # like the reference (utils.py:43-73 -> data.py ImageFolder raises on a missing / empty folder): a mistyped
+        # data_root must not silently train on noise and write checkpoints under the real model name
+        root = config.get("data_root")
+        folder = os.path.join(root, "trainA") if root else config.get("data_folder_train_a")
+        if not (folder and os.path.isdir(folder)):
+            sys.exit("training images not found (%r): fix data_root / data_folder_train_a in %s, or pass --synthetic "
+                     "to train on synthetic U(-1,1) batches" % (folder, opts.config))
         from aclgan_amd.data import get_all_data_loaders
         train_loader_a, train_loader_b, _, _ = get_all_data_loaders(config)      # train.py:43
         epoch = lambda: zip(train_loader_a, train_loader_b)                      # train.py:66
         print("data: %d / %d training images, device input pipeline" % (len(train_loader_a.source), len(train_loader_b.source)))
-    else:
-        epoch = synthetic_epoch
-        print("data: synthetic U(-1,1) batches")
     while True:
         for it, (images_a, images_b) in enumerate(epoch()):
             t0 = time.time()
