@@ -294,10 +294,17 @@ def main():
         log("kernel probe done; cpu baseline next")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes a version banner through C stdio (block-buffered when stdout is a file): flush it on every rank first,
+    # so that rank 0's JSON line is the LAST line of the job's stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if rank == 0:
+        time.sleep(0.2 if world > 1 else 0.0)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -7,9 +7,9 @@ The small-size tests (tests/test_gpu_step.py) never reach the launch shapes that
 oracle (oracle/aclgan_oracle.py, pinned to the reference by tests/golden) and are compared directly:
 
   * forward tensors (contents, styles, decoder outputs after the focus blend, the consistency pass,
-    discriminator maps)                                       <= 1e-3 rel (north-star tolerance)
-  * the 16 reported losses                                    <= 1e-3 rel ('size' losses 2e-2)
-  * one dis_update + one gen_update: every gradient tensor    <= GTOL relative L2 (smooth fixture:
+    discriminator maps)                                       <= 1e-4 rel (north-star tolerance: 1e-3)
+  * the 16 reported losses                                    <= 1e-4 rel ('size' losses 2e-2)
+  * one dis_update + one gen_update: every gradient tensor    <= 5e-3 relative L2 (smooth fixture:
     focus_epsilon 0.5, see tests/golden/make_golden.py for why the default 0.01 is ill-conditioned)
 
 Oracle cost on the GPU box's host cores: ~4 s per 256^2 sample-step, so the whole file is a few minutes.
@@ -23,9 +23,9 @@ from oracle import aclgan_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-GTOL = 1e-2          # per-tensor relative L2 of the gradients
-FTOL = 1e-3          # forward tensors, max-abs relative
-LTOL = 1e-3          # losses
+GTOL = 5e-3          # per-tensor relative L2 of the gradients; measured worst 2.8e-3 (profiles/r02_fullsize_parity_tests.log)
+FTOL = 1e-4          # forward tensors, max-abs relative (north star: 1e-3; measured worst 1.6e-5)
+LTOL = 1e-4          # losses (measured worst 4e-7)
 
 
 @pytest.fixture(scope="module")
