@@ -50,6 +50,7 @@ class ImageDesc(C.Structure):
 
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 NORM = {"none": 0, "in": 1, "adain": 2, "ln": 3}
+DTYPE = {"fp32": 0, "bf16": 1, "fp16": 2}
 GROUP_GEN, GROUP_DIS = 0, 1
 NETS = {"gen_AB": 0, "gen_BA": 1, "dis_A": 2, "dis_B": 3, "dis_2": 4}
 LOSS_NAMES = [
@@ -89,6 +90,17 @@ SIGNATURES = {
     "aclgan_conv2d_fwd_ws": (ci, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "aclgan_conv2d_fwd_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_fwd_naive": (ci, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),
+    "aclgan_set_compute_dtype": (ci, [vp, ci]),
+    "aclgan_bind_params16": (ci, [vp, ci, vp, vp]),
+    "aclgan_bind_loss_scale": (ci, [vp, vp]),
+    "aclgan_conv16_eligible": (ci, [C.POINTER(ConvDesc), ci]),
+    "aclgan_pack_weights16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "aclgan_conv2d_fwd16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp, vp]),
+    "aclgan_conv2d_dgrad16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp, vp]),
+    "aclgan_conv2d_wgrad16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp]),
+    "aclgan_conv2d_fwd16_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
+    "aclgan_conv2d_dgrad16_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
+    "aclgan_conv2d_wgrad16_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_dgrad": (ci, [C.POINTER(ConvDesc), vp, vp, vp, vp, ci, vp]),
     "aclgan_conv2d_dgrad_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_wgrad": (ci, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp]),

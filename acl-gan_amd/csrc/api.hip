@@ -25,7 +25,7 @@ using namespace aclgan;
 
 extern "C" {
 
-int aclgan_version(void) { return 100; }   // 0.1.0
+int aclgan_version(void) { return 200; }   // 0.2.0: 16-bit MFMA path, gradient buckets
 const char* aclgan_last_error(void) { return g_err; }
 
 int aclgan_conv2d_fwd(const aclgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* stream) {
@@ -85,6 +85,57 @@ int aclgan_conv2d_wgrad_ws(const aclgan_conv_desc* d, const float* x, const floa
     if (rc) return rc;
     ACL_REQUIRE(x && dy, "conv2d_wgrad_ws: null buffer");
     return conv_wgrad(g, x, dy, dw, db, (hipStream_t)stream, scratch);
+}
+
+// ---- 16-bit MFMA operators ----
+int aclgan_conv16_eligible(const aclgan_conv_desc* d, int which) {
+    ConvGeom g;
+    if (make_geom(d, &g) || which < 0 || which > 2) return 0;
+    return conv16_eligible(g, which) ? 1 : 0;
+}
+int aclgan_pack_weights16(const float* w, void* w16, void* w16t, int Co, int taps, int Ci, int dtype, void* stream) {
+    ACL_REQUIRE(w && Co > 0 && taps > 0 && Ci > 0, "pack_weights16: bad arguments");
+    const int64_t n = (int64_t)Co * taps * Ci;
+    ACL_REQUIRE(n % 4 == 0, "pack_weights16: Co*taps*Ci must be a multiple of 4");
+    if (w16) { const int rc = cast_flat16(w, w16, n, dtype, (hipStream_t)stream); if (rc) return rc; }
+    if (w16t) {
+        const int64_t off = 0;
+        const int rc = transpose_flat16(w, w16t, &off, &Co, &taps, &Ci, 1, dtype, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ACLGAN_OK;
+}
+size_t aclgan_conv2d_fwd16_scratch_bytes(const aclgan_conv_desc* d) { ConvGeom g; return make_geom(d, &g) ? 0 : conv_fwd16_scratch_bytes(g); }
+size_t aclgan_conv2d_dgrad16_scratch_bytes(const aclgan_conv_desc* d) { ConvGeom g; return make_geom(d, &g) ? 0 : conv_dgrad16_scratch_bytes(g); }
+size_t aclgan_conv2d_wgrad16_scratch_bytes(const aclgan_conv_desc* d) { ConvGeom g; return make_geom(d, &g) ? 0 : conv_wgrad16_scratch_bytes(g); }
+int aclgan_conv2d_fwd16(const aclgan_conv_desc* d, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y,
+                        void* scratch, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(x && w16 && y, "conv2d_fwd16: null buffer");
+    rc = conv_fwd16(g, dtype, x, w, w16, bias, y, scratch, (hipStream_t)stream);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_fwd16: no 16-bit kernel for this shape (Cin, Cout must be multiples of 32)");
+    return rc;
+}
+int aclgan_conv2d_dgrad16(const aclgan_conv_desc* d, int dtype, const float* dy, const float* w, const void* w16t, float* dx, int accumulate,
+                          void* scratch, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(dy && w16t && dx, "conv2d_dgrad16: null buffer");
+    rc = conv_dgrad16(g, dtype, dy, w, w16t, dx, accumulate, scratch, (hipStream_t)stream);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_dgrad16: no 16-bit kernel for this shape (Cin, Cout must be multiples of 32)");
+    return rc;
+}
+int aclgan_conv2d_wgrad16(const aclgan_conv_desc* d, int dtype, const float* x, const float* dy, float* dw, float* db, void* scratch, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(x && dy && dw, "conv2d_wgrad16: null buffer");
+    rc = conv_wgrad16(g, dtype, x, dy, dw, db, scratch, (hipStream_t)stream);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_wgrad16: no 16-bit kernel for this shape (Cin, Cout must be multiples of 64)");
+    return rc;
 }
 
 size_t aclgan_norm_scratch_bytes(int B, int HW, int C) { return norm_scratch_bytes(B, HW, C); }

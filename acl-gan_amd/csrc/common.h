@@ -57,6 +57,20 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
 // also accumulates the bias gradient into db when db != nullptr
 int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st);
 
+// 16-bit MFMA kernels (conv_fast16.hip): operands rounded to bf16 / fp16, fp32 accumulation and outputs.
+// which: 0 forward, 1 dgrad, 2 wgrad.  EUNSUPPORTED when the shape is not eligible.
+bool conv16_eligible(const ConvGeom& g, int which);
+size_t conv_fwd16_scratch_bytes(const ConvGeom& g);
+size_t conv_dgrad16_scratch_bytes(const ConvGeom& g);
+size_t conv_wgrad16_scratch_bytes(const ConvGeom& g);
+// w: fp32 OHWI master weights (only read by the sub-pixel path, to merge the phase filters before rounding); w16: OHWI 16-bit pack
+int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st);
+// w16t: 16-bit pack transposed to [tap][cin][cout]; dx is complete on return (interior + mirrored halo)
+int conv_dgrad16(const ConvGeom& g, int dtype, const float* dy, const float* w, const void* w16t, float* dx, int accumulate, void* scratch, hipStream_t st);
+int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
+int cast_flat16(const float* src, void* dst, int64_t n, int dtype, hipStream_t st);
+int transpose_flat16(const float* base, void* base_t, const int64_t* offs, const int* co, const int* taps, const int* ci, int n, int dtype, hipStream_t st);
+
 // direct VALU kernels for the 64->4 channel 7x7 output conv (conv_small.hip); EUNSUPPORTED otherwise
 int conv_fwd_small(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
 int conv_wgrad_small(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr);
@@ -96,13 +110,18 @@ int focus_blend_fwd(int B, int HW, const float* dec4, const float* bg, float* ou
 int focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const float* d_out, const float* d_pair,
                     float* d_dec4, float* d_bg, int bg_accumulate, hipStream_t st);
 // LSGAN (networks.py:67,83,98): loss_slot += weight*mean((o-t)^2); d_o = weight*2(o-t)/n*gscale (if d_o != null)
-int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st);
+// lscale (optional, device): fp16 dynamic loss scale; the gradient seed is multiplied by lscale[0], the reported loss is not
+int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st, const float* lscale = nullptr);
 // L1 (trainer.py:61-62): loss_slot = mean|a[..,:3] - b|; a has a_stride channels (4: decoder output), b 3 channels.
-int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st);
-// focus losses (trainer.py:146-158): sums[0]=sum m, sums[1]=sum 1/(|m-.5|+eps) over the mask channel (ch3 of dec4)
-int focus_sums(const float* dec4, int64_t npix, float eps, float* sums, hipStream_t st);
-// writes size/digit into loss slots and adds the focus gradient into d_dec4 channel 3
-int focus_loss_finish(const float* dec4, int64_t npix, const float* sums, float delta, float upper, float lower, float eps,
-                      float scale, float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st);
+int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st, const float* lscale = nullptr);
+// focus losses (trainer.py:146-158).  focus_sums: per-workgroup partials part[2*blk] = sum(m - upper), part[2*blk+1] =
+// sum 1/(|m-.5|+eps) over the mask channel (ch3 of dec4); part holds 2*focus_sums_blocks(npix) floats
+int focus_sums_blocks(int64_t npix);
+int focus_sums(const float* dec4, int64_t npix, float eps, float upper, float* part, hipStream_t st);
+// adds the partials in order, writes size/digit into the loss slots and adds the focus gradient into d_dec4 channel 3
+int focus_loss_finish(const float* dec4, int64_t npix, const float* part, float delta, float upper, float lower, float eps,
+                      float scale, float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st, const float* lscale = nullptr);
+// Adam under fp16 dynamic loss scaling: overflow scan, update with g/S (or skip), scale update -- all on the device
+int adam_flat_scaled(float* p, const float* g, float* m, float* v, int64_t n, const aclgan_adam* o, int step, float* state, int group, hipStream_t st);
 
 }  // namespace aclgan

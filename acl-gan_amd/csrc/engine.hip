@@ -58,6 +58,8 @@ struct PW {   // a (weight, bias) pair inside a flat group
     const float* w = nullptr; const float* b = nullptr;
     float* dw = nullptr; float* db = nullptr;
     int64_t nw = 0, nb = 0;   // element counts (gradient-bucket bookkeeping)
+    const unsigned short* w16 = nullptr;    // 16-bit packs of w (same layout) and its [tap][cin][cout] transpose
+    const unsigned short* w16t = nullptr;
 };
 
 // one backward closure + the ranges of the trained group's flat gradient buffer it writes
@@ -82,6 +84,13 @@ struct aclgan_ctx {
     size_t top = 0, peak = 0;
     std::vector<Act*> acts;
     std::vector<TapeOp> tape;
+    // reduced-precision compute (aclgan_set_compute_dtype / aclgan_bind_params16 / aclgan_bind_loss_scale)
+    int dtype = ACLGAN_DTYPE_FP32;
+    unsigned short* w16[2] = {nullptr, nullptr};
+    unsigned short* w16t[2] = {nullptr, nullptr};
+    float* lscale = nullptr;
+    std::vector<int64_t> cv_off[2];          // conv tensors of each group: offset / Cout / taps / Cin (transposed pack)
+    std::vector<int> cv_co[2], cv_taps[2], cv_ci[2];
     int trained = -1;          // group whose gradients this step produces (-1: forward only)
     bool fire_dry = false;     // aclgan_bucket_schedule: invoke the bucket callback during a dry run
     // data-parallel gradient buckets (aclgan_set_grad_buckets / aclgan_set_bucket_callback)
@@ -237,6 +246,10 @@ PW aclgan_ctx::pw(int group, int net, const std::string& key, bool with_bias) co
     PW p;
     p.w = param(group, net, key + ".weight"); p.dw = gradp(group, net, key + ".weight"); p.nw = numel_of(group, net, key + ".weight");
     if (with_bias) { p.b = param(group, net, key + ".bias"); p.db = gradp(group, net, key + ".bias"); p.nb = numel_of(group, net, key + ".bias"); }
+    if (dtype != ACLGAN_DTYPE_FP32 && p.w && w16[group] && w16t[group]) {
+        const int64_t off = p.w - groups[group].param;
+        p.w16 = w16[group] + off; p.w16t = w16t[group] + off;
+    }
     return p;
 }
 
@@ -267,12 +280,17 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     const bool want_grad = train_w || in->need_grad || ns.dw != nullptr;
     Act* co = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad);
     NEED(co->d); if (want_grad) NEED(co->g);
+    // 16-bit MFMA path (compute dtype bf16 / fp16): per operator, whenever the shape has a 16-bit kernel
+    const int dt = c.dtype;
+    const bool h16 = dt != ACLGAN_DTYPE_FP32 && W.w16 != nullptr;
+    const bool f16 = h16 && conv16_eligible(g, 0), d16 = h16 && conv16_eligible(g, 1), w16 = h16 && conv16_eligible(g, 2);
     {
         const size_t mark = c.top;
         void* fscr = nullptr;
-        const size_t fb = conv_fwd_scratch_bytes(g);   // merged phase weights of the sub-pixel path (upsample + 5x5 layers)
+        const size_t fb = f16 ? conv_fwd16_scratch_bytes(g) : conv_fwd_scratch_bytes(g);   // merged phase weights (upsample + 5x5 layers), split-K partials
         if (fb) { fscr = c.alloc(fb); NEED(fscr); }
-        RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr));
+        if (f16) RUN(conv_fwd16(g, dt, in->d, W.w, W.w16, W.b, co->d, fscr, c.st));
+        else RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr));
         c.top = mark;
     }
     Act* out = co;
@@ -311,16 +329,18 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         if (train_w) {
             const size_t mark = c.top;
             void* wscr = nullptr;
-            const size_t wb = conv_wgrad_scratch_bytes(g);
+            const size_t wb = w16 ? conv_wgrad16_scratch_bytes(g) : conv_wgrad_scratch_bytes(g);
             if (wb) { wscr = c.alloc(wb); NEED(wscr); }
-            RUN(conv_wgrad(g, in->d, co->g, W.dw, W.db, c.st, wscr));
+            if (w16) RUN(conv_wgrad16(g, dt, in->d, co->g, W.dw, W.db, wscr, c.st));
+            else RUN(conv_wgrad(g, in->d, co->g, W.dw, W.db, c.st, wscr));
             c.top = mark;
         }
         if (in->need_grad) {
             const size_t mark = c.top;
-            void* scr = c.alloc(conv_dgrad_scratch_bytes(g));
+            void* scr = c.alloc(d16 ? conv_dgrad16_scratch_bytes(g) + 256 : conv_dgrad_scratch_bytes(g));
             NEED(scr);
-            RUN(conv_dgrad(g, co->g, W.w, in->g, scr, in->gw ? 1 : 0, c.st));
+            if (d16) RUN(conv_dgrad16(g, dt, co->g, W.w, W.w16t, in->g, in->gw ? 1 : 0, scr, c.st));
+            else RUN(conv_dgrad(g, co->g, W.w, in->g, scr, in->gw ? 1 : 0, c.st));
             mark_written(in);
             c.top = mark;
         }
@@ -526,7 +546,7 @@ static int dis_lsgan(aclgan_ctx& c, int net, bool train, Act* x, int nb, const s
         const int n = nb * o->H * o->W * o->C;
         for (size_t i = 0; i < segs.size(); ++i)
             RUN(lsgan_loss(o->d + (size_t)i * n, n, segs[i].target, segs[i].weight, segs[i].slot,
-                           o->need_grad ? o->g + (size_t)i * n : nullptr, segs[i].gscale, c.st));
+                           o->need_grad ? o->g + (size_t)i * n : nullptr, segs[i].gscale, c.st, c.lscale));
         if (o->need_grad) mark_written(o);
     }
     return ACLGAN_OK;
@@ -586,6 +606,20 @@ __global__ void gen_total_kernel(float* L, aclgan_hparams hp, float focus_scale)
 }
 __global__ void dis_total_kernel(float* L, aclgan_hparams hp) {
     L[ACLGAN_L_DIS_TOTAL] = hp.gan_w * L[ACLGAN_L_DIS_A] + hp.gan_w * L[ACLGAN_L_DIS_B] + hp.gan_cw * L[ACLGAN_L_DIS_2];
+}
+
+// Refresh the 16-bit weight packs from the fp32 master parameters (both groups: each update runs the other group's
+// networks forward / dgrad-only).  ~55 M elements read once, 2 x 2 bytes written: ~0.1 ms against a step of tens of ms,
+// and it makes the packs immune to whatever touched the flat buffers between calls (Adam, load_state_dict, broadcast).
+static int pack_params(aclgan_ctx& c) {
+    if (c.dtype == ACLGAN_DTYPE_FP32 || c.dry) return ACLGAN_OK;
+    for (int g = 0; g < 2; ++g) {
+        if (!c.w16[g] || !c.w16t[g]) { set_error("compute dtype is 16-bit but aclgan_bind_params16 was not called for group %d", g); return ACLGAN_EINVAL; }
+        CHK(cast_flat16(c.groups[g].param, c.w16[g], c.groups[g].numel, c.dtype, c.st));
+        CHK(transpose_flat16(c.groups[g].param, c.w16t[g], c.cv_off[g].data(), c.cv_co[g].data(), c.cv_taps[g].data(), c.cv_ci[g].data(),
+                             (int)c.cv_off[g].size(), c.dtype, c.st));
+    }
+    return ACLGAN_OK;
 }
 
 static int input_act(aclgan_ctx& c, const float* nchw, int B, int C, int H, int W, Act** out) {
@@ -666,14 +700,14 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     }
     const int sd = c.arch.gen_style_dim;
     const int AB = ACLGAN_NET_GEN_AB, BA = ACLGAN_NET_GEN_BA;
-    float* sums = c.allocf(8);
+    const int nfs = 2 * focus_sums_blocks((int64_t)B * H * W);   // per-workgroup partials of the focus sums, one set per mask
+    float* sums = c.allocf((int64_t)3 * nfs);
     NEED(sums);
     if (!c.dry) {
         hipError_t e = hipMemsetAsync(L, 0, sizeof(float) * (ACLGAN_L_GEN_TOTAL + 1), c.st);
         if (e != hipSuccess) return hip_fail(e, "memset losses");
-        e = hipMemsetAsync(sums, 0, sizeof(float) * 8, c.st);
-        if (e != hipSuccess) return hip_fail(e, "memset sums");
     }
+    CHK(pack_params(c));
     Act *xa, *xb, *z1, *z2, *z3;
     CHK(input_act(c, x_a, B, 3, H, W, &xa));
     CHK(input_act(c, x_b, B, 3, H, W, &xb));
@@ -713,13 +747,13 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         {dA4, ACLGAN_L_GEN_FOCUS_A_SIZE, ACLGAN_L_GEN_FOCUS_A_DIGIT},
         {dA24, ACLGAN_L_GEN_FOCUS_A2_SIZE, ACLGAN_L_GEN_FOCUS_A2_DIGIT}};
     for (int i = 0; i < 3; ++i) {
-        RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, sums + 2 * i, c.st));
-        RUN(focus_loss_finish(fl[i].a->d, npix, sums + 2 * i, hp.focus_delta, hp.focus_upper, hp.focus_lower, hp.focus_epsilon, fscale,
-                              L + fl[i].size_slot, L + fl[i].digit_slot, fl[i].a->g, c.st));
+        RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, hp.focus_upper, sums + (size_t)i * nfs, c.st));
+        RUN(focus_loss_finish(fl[i].a->d, npix, sums + (size_t)i * nfs, hp.focus_delta, hp.focus_upper, hp.focus_lower, hp.focus_epsilon, fscale,
+                              L + fl[i].size_slot, L + fl[i].digit_slot, fl[i].a->g, c.st, c.lscale));
     }
     // identity losses (trainer.py:162-165)
-    RUN(l1_loss(rA4->d, 4, xa->d, npix, L + ACLGAN_L_IDT_A, rA4->g, hp.recon_x_w, 1, c.st));
-    RUN(l1_loss(rB4->d, 4, xb->d, npix, L + ACLGAN_L_IDT_B, rB4->g, hp.recon_x_w, 1, c.st));
+    RUN(l1_loss(rA4->d, 4, xa->d, npix, L + ACLGAN_L_IDT_A, rA4->g, hp.recon_x_w, 1, c.st, c.lscale));
+    RUN(l1_loss(rB4->d, 4, xb->d, npix, L + ACLGAN_L_IDT_B, rB4->g, hp.recon_x_w, 1, c.st, c.lscale));
     if (!c.dry) {
         hipLaunchKernelGGL(gen_total_kernel, dim3(1), dim3(1), 0, c.st, L, hp, fscale);
         ACL_CHECK_LAUNCH("gen_total_kernel");
@@ -738,6 +772,7 @@ static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         hipError_t e = hipMemsetAsync(L + ACLGAN_L_DIS_A, 0, sizeof(float) * 4, c.st);
         if (e != hipSuccess) return hip_fail(e, "memset losses");
     }
+    CHK(pack_params(c));
     Act *xa, *xb, *z1, *z2, *z3;
     CHK(input_act(c, x_a, B, 3, H, W, &xa));
     CHK(input_act(c, x_b, B, 3, H, W, &xb));
@@ -798,11 +833,33 @@ int aclgan_ctx_create(const aclgan_arch* arch, aclgan_ctx** out) {
     build_dis(c->groups[1], "dis_A", arch->input_dim_a, *arch);
     build_dis(c->groups[1], "dis_B", arch->input_dim_a, *arch);
     build_dis(c->groups[1], "dis_2", arch->input_dim_b, *arch);
+    for (int g = 0; g < 2; ++g)
+        for (const TensorInfo& t : c->groups[g].tensors)
+            if (t.ndim == 4) {
+                c->cv_off[g].push_back(t.offset); c->cv_co[g].push_back(t.shape[0]);
+                c->cv_taps[g].push_back(t.shape[2] * t.shape[3]); c->cv_ci[g].push_back(t.shape[1]);
+            }
     *out = c;
     return ACLGAN_OK;
 }
 
 void aclgan_ctx_destroy(aclgan_ctx* ctx) { delete ctx; }
+
+int aclgan_set_compute_dtype(aclgan_ctx* ctx, int dtype) {
+    ACL_REQUIRE(ctx && dtype >= ACLGAN_DTYPE_FP32 && dtype <= ACLGAN_DTYPE_FP16, "bad ctx / dtype %d", dtype);
+    ctx->dtype = dtype;
+    return ACLGAN_OK;
+}
+int aclgan_bind_params16(aclgan_ctx* ctx, int group, void* w16, void* w16t) {
+    ACL_REQUIRE(ctx && group >= 0 && group <= 1, "bad ctx/group");
+    ctx->w16[group] = (unsigned short*)w16; ctx->w16t[group] = (unsigned short*)w16t;
+    return ACLGAN_OK;
+}
+int aclgan_bind_loss_scale(aclgan_ctx* ctx, float* state) {
+    ACL_REQUIRE(ctx, "null ctx");
+    ctx->lscale = state;
+    return ACLGAN_OK;
+}
 
 int64_t aclgan_group_numel(const aclgan_ctx* ctx, int group) {
     if (!ctx || group < 0 || group > 1) return -1;
@@ -958,6 +1015,7 @@ int aclgan_adam_step(aclgan_ctx* ctx, int group, const aclgan_adam* opt, int ste
     ACL_REQUIRE(ctx && opt && group >= 0 && group <= 1, "bad ctx/group/opt");
     Group& g = ctx->groups[group];
     ACL_REQUIRE(g.param && g.grad && g.m && g.v, "param/grad/exp_avg/exp_avg_sq must all be bound");
+    if (ctx->lscale) return adam_flat_scaled(g.param, g.grad, g.m, g.v, g.numel, opt, step, ctx->lscale, group, (hipStream_t)stream);
     return adam_flat(g.param, g.grad, g.m, g.v, g.numel, opt, step, (hipStream_t)stream);
 }
 
@@ -975,6 +1033,8 @@ int aclgan_gen_encode(aclgan_ctx* ctx, int net, const float* x, int B, int H, in
     if (rc) return rc;
     ACL_REQUIRE(net == ACLGAN_NET_GEN_AB || net == ACLGAN_NET_GEN_BA, "encode: net must be a generator");
     aclgan_ctx& c = *ctx;
+    rc = pack_params(c);
+    if (rc) return rc;
     Act *xa = nullptr, *cc = nullptr, *ss = nullptr;
     rc = input_act(c, x, B, 3, H, W, &xa);
     if (!rc && content) { rc = content_encode(c, net, false, xa, &cc); if (!rc) rc = nhwc_to_nchw(cc->d, content, cc->B, cc->C, cc->H, cc->W, c.st); }
@@ -991,6 +1051,8 @@ int aclgan_gen_decode(aclgan_ctx* ctx, int net, const float* content, const floa
     if (rc) return rc;
     ACL_REQUIRE(net == ACLGAN_NET_GEN_AB || net == ACLGAN_NET_GEN_BA, "decode: net must be a generator");
     aclgan_ctx& c = *ctx;
+    rc = pack_params(c);
+    if (rc) return rc;
     const int C = c.arch.gen_dim << c.arch.gen_n_downsample;
     Act *cc = nullptr, *ss = nullptr, *o = nullptr;
     rc = input_act(c, content, B, C, h, w, &cc);
@@ -1006,6 +1068,8 @@ int aclgan_dis_forward(aclgan_ctx* ctx, int net, const float* x, int B, int H, i
     if (rc) return rc;
     ACL_REQUIRE(net >= ACLGAN_NET_DIS_A && net <= ACLGAN_NET_DIS_2, "dis_forward: net must be a discriminator");
     aclgan_ctx& c = *ctx;
+    rc = pack_params(c);
+    if (rc) return rc;
     const int Cin = net == ACLGAN_NET_DIS_2 ? c.arch.input_dim_b : c.arch.input_dim_a;
     Act* xa = nullptr;
     std::vector<Act*> o;

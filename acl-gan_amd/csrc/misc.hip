@@ -140,6 +140,50 @@ int adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const acl
     return ACLGAN_OK;
 }
 
+// ---- Adam under fp16 dynamic loss scaling (state layout: include/aclgan_hip.h, aclgan_bind_loss_scale) ----
+__global__ void grad_check_kernel(const float* __restrict__ g, int64_t n, float* state) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= !isfinite(g[i]);
+    if (bad) state[3] = 1.f;   // benign race: every writer stores the same value
+}
+__global__ void adam_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   int64_t n, float b1, float b2, float eps, float wd, float lr, int step_host, const float* __restrict__ state, int group) {
+    if (state[3] != 0.f) return;                   // overflow somewhere in this group's gradients: skip the update
+    const int step = step_host - (int)state[4 + group];   // skipped updates do not advance Adam's bias correction
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    const float step_size = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)), inv = state[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float pv = p[i];
+        const float gv = fmaf(wd, pv, g[i] * inv);
+        const float mv = fmaf(b1, m[i], (1.f - b1) * gv);
+        const float vv = fmaf(b2, v[i], (1.f - b2) * gv * gv);
+        m[i] = mv; v[i] = vv;
+        p[i] = pv - step_size * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    }
+}
+__global__ void scale_update_kernel(float* state, int group) {
+    if (state[3] != 0.f) {
+        state[0] = fmaxf(state[0] * 0.5f, 1.f); state[2] = 0.f; state[4 + group] += 1.f;
+    } else {
+        state[2] += 1.f;
+        const float interval = state[6] > 0.f ? state[6] : 2000.f;
+        if (state[2] >= interval) { state[0] = fminf(state[0] * 2.f, 16777216.f); state[2] = 0.f; }
+    }
+    state[1] = 1.f / state[0];
+    state[3] = 0.f;
+}
+int adam_flat_scaled(float* p, const float* g, float* m, float* v, int64_t n, const aclgan_adam* o, int step, float* state, int group, hipStream_t st) {
+    ACL_REQUIRE(step >= 1 && state && (group == 0 || group == 1), "adam (loss-scaled): bad arguments");
+    const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 16384);
+    hipLaunchKernelGGL(grad_check_kernel, dim3(grid), dim3(256), 0, st, g, n, state);
+    ACL_CHECK_LAUNCH("grad_check_kernel");
+    hipLaunchKernelGGL(adam_scaled_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, o->beta1, o->beta2, o->eps, o->weight_decay, o->lr, step, state, group);
+    ACL_CHECK_LAUNCH("adam_scaled_kernel");
+    hipLaunchKernelGGL(scale_update_kernel, dim3(1), dim3(1), 0, st, state, group);
+    ACL_CHECK_LAUNCH("scale_update_kernel");
+    return ACLGAN_OK;
+}
+
 // ---- layout conversion at the boundary ----
 __global__ void nchw2nhwc_kernel(const float* __restrict__ s, float* __restrict__ d, int C, int HW, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -327,8 +371,9 @@ int focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const flo
 
 // ---- LSGAN: loss_slot += weight*mean((o-t)^2); d_o = gscale*weight*2(o-t)/n ----
 __global__ void __launch_bounds__(256) lsgan_kernel(const float* __restrict__ o, int n, float target, float weight, float* loss_slot,
-                                                    float* __restrict__ d_o, float gscale) {
+                                                    float* __restrict__ d_o, float gscale, const float* __restrict__ lscale) {
     float s = 0.f;
+    if (lscale) gscale *= lscale[0];   // fp16 dynamic loss scale (device resident)
     const float k = gscale * weight * 2.f / (float)n;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float d = o[i] - target;
@@ -338,16 +383,17 @@ __global__ void __launch_bounds__(256) lsgan_kernel(const float* __restrict__ o,
     s = block_sum_t0(s);
     if (threadIdx.x == 0) atomicAdd(loss_slot, weight * s / (float)n);
 }
-int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st) {
-    hipLaunchKernelGGL(lsgan_kernel, dim3(1), dim3(256), 0, st, o, n, target, weight, loss_slot, d_o, gscale);
+int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st, const float* lscale) {
+    hipLaunchKernelGGL(lsgan_kernel, dim3(1), dim3(256), 0, st, o, n, target, weight, loss_slot, d_o, gscale, lscale);
     ACL_CHECK_LAUNCH("lsgan_kernel");
     return ACLGAN_OK;
 }
 
 // ---- L1: loss_slot += mean|a[:, :3] - b|; d_a[pix][0..2] (+)= gscale*sign/N, channel 3 untouched (a_stride 4) ----
 __global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ a, int a_stride, const float* __restrict__ b, int64_t npix,
-                                                 float* loss_slot, float* __restrict__ d_a, float gscale, int d_acc) {
+                                                 float* loss_slot, float* __restrict__ d_a, float gscale, int d_acc, const float* __restrict__ lscale) {
     float s = 0.f;
+    if (lscale) gscale *= lscale[0];
     const float inv = 1.f / (3.f * (float)npix);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
 #pragma unroll
@@ -364,39 +410,52 @@ __global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ a, in
     s = block_sum_t0(s);
     if (threadIdx.x == 0) atomicAdd(loss_slot, s * inv);
 }
-int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(l1_kernel, dim3((int)std::min<int64_t>(cdiv64(npix, 256), 1024)), dim3(256), 0, st, a, a_stride, b, npix, loss_slot, d_a, gscale, d_accumulate);
+int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st, const float* lscale) {
+    hipLaunchKernelGGL(l1_kernel, dim3((int)std::min<int64_t>(cdiv64(npix, 256), 1024)), dim3(256), 0, st, a, a_stride, b, npix, loss_slot, d_a, gscale, d_accumulate, lscale);
     ACL_CHECK_LAUNCH("l1_kernel");
     return ACLGAN_OK;
 }
 
 // ---- focus losses (trainer.py:146-158) ----
-__global__ void __launch_bounds__(256) focus_sums_kernel(const float4* __restrict__ dec4, int64_t npix, float eps, float* sums) {
+// size = delta*(relu(sum(m - upper))^2 + relu(sum(lower - m))^2): the reference sums ~5e5 values near 0.5 and squares the
+// (200x-cancelling) result.  Here every term is centred BEFORE it is summed (d = m - upper; sum(lower - m) = N*(lower -
+// upper) - sum d), each workgroup stores its partial, and the finish kernel adds the partials in a fixed order in double:
+// no cancellation against N*upper, no atomics -> the two 'size' losses are reproducible bit for bit.
+__global__ void __launch_bounds__(256) focus_sums_kernel(const float4* __restrict__ dec4, int64_t npix, float eps, float upper, float* part) {
     float s = 0.f, q = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
         const float m = (dec4[i].w + 1.f) * 0.5f;
-        s += m;
+        s += m - upper;
         q += 1.f / (fabsf(m - 0.5f) + eps);
     }
     s = block_sum_t0(s);
     q = block_sum_t0(q);
-    if (threadIdx.x == 0) { atomicAdd(sums, s); atomicAdd(sums + 1, q); }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = q; }
 }
-int focus_sums(const float* dec4, int64_t npix, float eps, float* sums, hipStream_t st) {
-    hipLaunchKernelGGL(focus_sums_kernel, dim3((int)std::min<int64_t>(cdiv64(npix, 256), 512)), dim3(256), 0, st, (const float4*)dec4, npix, eps, sums);
+int focus_sums_blocks(int64_t npix) { return (int)std::min<int64_t>(cdiv64(npix, 256), 512); }
+int focus_sums(const float* dec4, int64_t npix, float eps, float upper, float* part, hipStream_t st) {
+    hipLaunchKernelGGL(focus_sums_kernel, dim3(focus_sums_blocks(npix)), dim3(256), 0, st, (const float4*)dec4, npix, eps, upper, part);
     ACL_CHECK_LAUNCH("focus_sums_kernel");
     return ACLGAN_OK;
 }
-__global__ void focus_finish_kernel(const float4* __restrict__ dec4, int64_t npix, const float* __restrict__ sums, float delta,
+__global__ void focus_finish_kernel(const float4* __restrict__ dec4, int64_t npix, const float* __restrict__ part, int nblk, float delta,
                                     float upper, float lower, float eps, float scale, float* size_slot, float* digit_slot,
-                                    float4* __restrict__ d_dec4) {
-    const float N = (float)npix, S = sums[0];
-    const float hi = fmaxf(S - N * upper, 0.f), lo = fmaxf(N * lower - S, 0.f);
+                                    float4* __restrict__ d_dec4, const float* __restrict__ lscale) {
+    __shared__ double tot[2];
+    if (threadIdx.x < 2) {       // every workgroup repeats the same ordered sum of <= 512 partials
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += (double)part[2 * b + threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const double D = tot[0];                                   // sum(m - upper)
+    const float hi = (float)fmax(D, 0.0), lo = (float)fmax((double)npix * ((double)lower - (double)upper) - D, 0.0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *size_slot = delta * (hi * hi + lo * lo);
-        *digit_slot = sums[1];
+        *digit_slot = (float)tot[1];
     }
     if (!d_dec4) return;
+    if (lscale) scale *= lscale[0];
     const float gsize = 2.f * delta * (hi - lo);   // d size / d m_i
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
         const float m = (dec4[i].w + 1.f) * 0.5f;
@@ -406,10 +465,10 @@ __global__ void focus_finish_kernel(const float4* __restrict__ dec4, int64_t npi
         d_dec4[i].w += scale * 0.5f * gm;
     }
 }
-int focus_loss_finish(const float* dec4, int64_t npix, const float* sums, float delta, float upper, float lower, float eps, float scale,
-                      float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st) {
-    hipLaunchKernelGGL(focus_finish_kernel, dim3((int)std::min<int64_t>(cdiv64(npix, 256), 1024)), dim3(256), 0, st, (const float4*)dec4, npix, sums,
-                       delta, upper, lower, eps, scale, size_slot, digit_slot, (float4*)d_dec4);
+int focus_loss_finish(const float* dec4, int64_t npix, const float* part, float delta, float upper, float lower, float eps, float scale,
+                      float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st, const float* lscale) {
+    hipLaunchKernelGGL(focus_finish_kernel, dim3((int)std::min<int64_t>(cdiv64(npix, 256), 1024)), dim3(256), 0, st, (const float4*)dec4, npix, part,
+                       focus_sums_blocks(npix), delta, upper, lower, eps, scale, size_slot, digit_slot, (float4*)d_dec4, lscale);
     ACL_CHECK_LAUNCH("focus_finish_kernel");
     return ACLGAN_OK;
 }

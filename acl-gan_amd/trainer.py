@@ -187,17 +187,20 @@ class aclgan_Trainer:
         hp = hyperparameters
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.arch = arch_from_config(hp)
+        # compute dtype of the heavy convolutions (not in the reference, which is fp32 only): "fp32" | "bf16" | "fp16"
         self.compute_dtype = str(compute_dtype or hp.get("compute_dtype", "fp32"))
-        if self.compute_dtype != "fp32":
-            raise L.AclganError("compute_dtype=%r: only fp32 is built" % self.compute_dtype)
+        if self.compute_dtype not in L.DTYPE:
+            raise L.AclganError("compute_dtype=%r: expected one of %s" % (self.compute_dtype, sorted(L.DTYPE)))
         self._ctx = C.c_void_p()
         L.check(L.lib.aclgan_ctx_create(C.byref(self.arch), C.byref(self._ctx)), "ctx_create")
+        L.check(L.lib.aclgan_set_compute_dtype(self._ctx, L.DTYPE[self.compute_dtype]), "set_compute_dtype")
         self.style_dim = hp["gen"]["style_dim"]
         self.alpha = hp["alpha"]
         self.focus_lam = hp["focus_loss"]
         self._hp = hp
         # ---- flat buffers (one contiguous param / grad / exp_avg / exp_avg_sq per optimizer) ----
         self._tensors, self._param, self._grad, self._m, self._v = {}, {}, {}, {}, {}
+        self._w16, self._w16t = {}, {}
         for grp in (L.GROUP_GEN, L.GROUP_DIS):
             n = L.lib.aclgan_group_numel(self._ctx, grp)
             ents = []
@@ -216,6 +219,10 @@ class aclgan_Trainer:
             self._v[grp] = torch.zeros(n, device=self.device)
             L.check(L.lib.aclgan_bind_params(self._ctx, grp, L.ptr(self._param[grp]), L.ptr(self._grad[grp]),
                                              L.ptr(self._m[grp]), L.ptr(self._v[grp])), "bind_params")
+            if self.compute_dtype != "fp32":   # 16-bit weight packs, refreshed by the library from the fp32 master copy
+                self._w16[grp] = torch.zeros(n, dtype=torch.int16, device=self.device)
+                self._w16t[grp] = torch.zeros(n, dtype=torch.int16, device=self.device)
+                L.check(L.lib.aclgan_bind_params16(self._ctx, grp, L.ptr(self._w16[grp]), L.ptr(self._w16t[grp])), "bind_params16")
         d = self.arch.gen_dim << self.arch.gen_n_downsample
         self._dummy_buffers = {}
         for net in ("gen_AB", "gen_BA"):   # AdaIN running_mean/var: never used, but in the state_dict (networks.py:488-489)
@@ -244,6 +251,13 @@ class aclgan_Trainer:
         for n in L.LOSS_NAMES:
             setattr(self, n, torch.zeros((), device=self.device))
         self._zgen = None
+        # fp16: dynamic loss scaling, state resident on the device (include/aclgan_hip.h: aclgan_bind_loss_scale)
+        self._lscale = None
+        if self.compute_dtype == "fp16":
+            s0 = float(hp.get("loss_scale_init", 65536.0))
+            self._lscale = torch.tensor([s0, 1.0 / s0, 0, 0, 0, 0, float(hp.get("loss_scale_growth_interval", 2000)), 0],
+                                        dtype=torch.float32, device=self.device)
+            L.check(L.lib.aclgan_bind_loss_scale(self._ctx, L.ptr(self._lscale)), "bind_loss_scale")
         self._setup_data_parallel()
 
     def __del__(self):
@@ -317,6 +331,17 @@ class aclgan_Trainer:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         L.check(L.lib.aclgan_bind_workspace(self._ctx, L.ptr(self._ws), self._ws.numel()), "bind_workspace")
         self._ws_shape = key + (not forward_only,)
+
+    def loss_scale_state(self):
+        """fp16 only: {'scale', 'clean_updates', 'skipped_gen', 'skipped_dis'} (one device->host copy)."""
+        if self._lscale is None:
+            return None
+        v = self._lscale.cpu().tolist()
+        return {"scale": v[0], "clean_updates": int(v[2]), "skipped_gen": int(v[4]), "skipped_dis": int(v[5])}
+
+    def grad_scale(self):
+        """the factor the gradient buffers carry (fp16: the loss scale of the LAST update; else 1)"""
+        return 1.0 if self._lscale is None else float(self._lscale[0])
 
     def _draw_z(self, B):
         # three draws from the CPU generator, in the reference's order (trainer.py:99-101); data-parallel ranks use

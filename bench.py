@@ -127,7 +127,7 @@ def dominant_kernel_probe(L, dtype, reps=20):
         code = L.DTYPE[dtype]
         w16 = torch.empty(w.numel(), dtype=torch.int16, device="cuda")
         L.check(L.lib.aclgan_pack_weights16(L.ptr(w), L.ptr(w16), None, Cc, 9, Cc, code, st))
-        call = lambda: L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), code, L.ptr(x), L.ptr(w16), L.ptr(b), L.ptr(y), None, st))   # noqa: E731
+        call = lambda: L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), code, L.ptr(x), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), None, st))   # noqa: E731
         name = "conv_fwd16_kernel<%s> 8x64x64x256->256 3x3 (ResBlock conv)" % dtype
         extra = {"traffic": None, "algorithmic_bytes": 69.5e6 - w.numel() * 2}
     for _ in range(3):

@@ -47,6 +47,14 @@ extern "C" {
 #define ACLGAN_NORM_ADAIN 2
 #define ACLGAN_NORM_LN 3
 
+/* compute dtype of the heavy convolutions (NOT in the reference, which is fp32-only: BASELINE.json configs[2] / [4]).
+ * BF16 / FP16: both MFMA operands are rounded to the 16-bit type (round to nearest even), products accumulate in fp32
+ * (v_mfma_f32_32x32x16_bf16 / _f16); activations, gradients, master weights, Adam state, norm statistics and losses
+ * stay fp32.  FP16 training uses dynamic loss scaling (aclgan_bind_loss_scale). */
+#define ACLGAN_DTYPE_FP32 0
+#define ACLGAN_DTYPE_BF16 1
+#define ACLGAN_DTYPE_FP16 2
+
 /* parameter groups = the reference's two optimizers (trainer.py:37-42) */
 #define ACLGAN_GROUP_GEN 0
 #define ACLGAN_GROUP_DIS 1
@@ -120,6 +128,23 @@ int aclgan_tensor_info(const aclgan_ctx* ctx, int group, int index, char* name, 
                        int64_t* offset, int* shape4, int* ndim);
 int aclgan_bind_params(aclgan_ctx* ctx, int group, float* param, float* grad, float* exp_avg,
                        float* exp_avg_sq);
+
+/* ---- reduced-precision compute (ACLGAN_DTYPE_*) ----
+ * aclgan_set_compute_dtype: FP32 (default) or BF16 / FP16 for every convolution whose channel counts are multiples of
+ * 32 (64 for the weight gradient); the image-side layers (Cin 3/6, Cout 1/4) and the MLP stay on the fp32 kernels.
+ * aclgan_bind_params16: two caller-owned buffers of aclgan_group_numel(group) 16-bit elements per group -- w16 (same
+ * offsets and OHWI layout as the fp32 parameters) and w16t (conv weights transposed to [tap][cin][cout], read by
+ * dgrad).  The library refreshes them from the fp32 master copy at the start of every update / forward call. */
+int aclgan_set_compute_dtype(aclgan_ctx* ctx, int dtype);
+int aclgan_bind_params16(aclgan_ctx* ctx, int group, void* w16, void* w16t);
+/* fp16 dynamic loss scaling.  state: device float[8], caller-owned, zero-initialised except state[0]:
+ *   [0] scale S  [1] 1/S  [2] consecutive overflow-free updates  [3] overflow flag of the update in flight
+ *   [4],[5] updates skipped so far (gen, dis)  [6] growth interval (0: 2000)  [7] reserved
+ * Every loss-gradient seed is multiplied by S; aclgan_adam_step first scans the group's gradients, and -- all on the
+ * device, no host round trip -- either applies Adam with g/S or skips the update, halves S and counts the skip (the
+ * bias-correction step excludes skipped updates); S doubles after `growth interval` clean updates.  The gradient
+ * buffer read by the caller (e.g. for an all-reduce) holds S*g.  NULL unbinds. */
+int aclgan_bind_loss_scale(aclgan_ctx* ctx, float* state);
 
 /* activation workspace for one update at the given batch shape (bytes); bind before stepping */
 int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out);
@@ -195,6 +220,22 @@ int aclgan_conv2d_wgrad(const aclgan_conv_desc* d, const float* x, const float* 
 int aclgan_conv2d_wgrad_ws(const aclgan_conv_desc* d, const float* x, const float* dy, float* dw,
                            float* db, void* scratch, void* stream);
 size_t aclgan_conv2d_wgrad_scratch_bytes(const aclgan_conv_desc* d);
+/* ---- the same three operators on the 16-bit matrix cores (dtype = ACLGAN_DTYPE_BF16 / _FP16) ----
+ * which: 0 forward, 1 dgrad, 2 wgrad -> 1 when that operator has a 16-bit kernel for this shape */
+int aclgan_conv16_eligible(const aclgan_conv_desc* d, int which);
+/* fp32 OHWI weights [Co][taps][Ci] -> 16-bit packs: w16 (same layout) and/or w16t ([tap][ci][co]); either may be NULL */
+int aclgan_pack_weights16(const float* w, void* w16, void* w16t, int Co, int taps, int Ci, int dtype, void* stream);
+/* w: the fp32 weights (needed by the upsample+5x5 layers, whose phase filters are merged before rounding; else may be
+ * NULL).  scratch: aclgan_conv2d_*16_scratch_bytes (NULL allowed when that is 0) */
+int aclgan_conv2d_fwd16(const aclgan_conv_desc* d, int dtype, const float* x, const float* w, const void* w16,
+                        const float* bias, float* y, void* scratch, void* stream);
+int aclgan_conv2d_dgrad16(const aclgan_conv_desc* d, int dtype, const float* dy, const float* w, const void* w16t,
+                          float* dx, int accumulate, void* scratch, void* stream);
+int aclgan_conv2d_wgrad16(const aclgan_conv_desc* d, int dtype, const float* x, const float* dy, float* dw,
+                          float* db, void* scratch, void* stream);
+size_t aclgan_conv2d_fwd16_scratch_bytes(const aclgan_conv_desc* d);
+size_t aclgan_conv2d_dgrad16_scratch_bytes(const aclgan_conv_desc* d);
+size_t aclgan_conv2d_wgrad16_scratch_bytes(const aclgan_conv_desc* d);
 /* same three, but the plain one-thread-per-output kernels (no MFMA): on-device cross-check */
 int aclgan_conv2d_fwd_naive(const aclgan_conv_desc* d, const float* x, const float* w,
                             const float* bias, float* y, void* stream);
