@@ -226,15 +226,140 @@ def layer_norm_munit(x, gamma, beta):
     return y * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
 
 
+# --------------------------------------------------------------------------------------
+# emulation of the build's reduced-precision COMPUTE contract (NOT reference behaviour: the reference
+# is fp32 only).  Used by tests/test_gpu_step16.py to check that the bf16 / fp16 HIP path computes exactly
+# what acl-gan_amd/csrc/conv_fast16.hip states: for every convolution whose channel counts are multiples of
+# 32 (weight gradient: 64) both GEMM operands are rounded to the 16-bit type (round to nearest even), the
+# products accumulate in (at least) fp32, everything else stays fp32.  The sub-pixel path of the
+# "Upsample(2) + 5x5" layers rounds the MERGED 3x3 phase filters (forward / dgrad, interior pixels only).
+# --------------------------------------------------------------------------------------
+_QDT = None   # torch.bfloat16 / torch.float16 while emulating, else None (= the plain fp32 oracle)
+_QSCALE = 1.0  # fp16 loss scale S: every gradient that enters a 16-bit GEMM is S*dy (the build seeds the backward with S)
+
+
+class compute_dtype:
+    """with compute_dtype("bf16"): ... / with compute_dtype("fp16", loss_scale=65536.0): ...
+    conv_block emulates the 16-bit MFMA contract inside the block (gradients come out UNscaled)."""
+
+    def __init__(self, name, loss_scale=1.0):
+        self.dt = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[name]
+        self.scale = float(loss_scale)
+
+    def __enter__(self):
+        global _QDT, _QSCALE
+        self.prev, _QDT, _QSCALE = (_QDT, _QSCALE), self.dt, self.scale
+
+    def __exit__(self, *a):
+        global _QDT, _QSCALE
+        _QDT, _QSCALE = self.prev
+
+
+def _q(t):
+    return t.to(_QDT).to(t.dtype)
+
+
+def _qg(dy):
+    """a gradient operand: rounded at the loss scale it carries in the build"""
+    return _q(dy * _QSCALE) / _QSCALE
+
+
+def _plain_conv(x, w, stride, pad, upsample):
+    if upsample:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if pad > 0:
+        x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
+    return F.conv2d(x, w, None, stride=stride)
+
+
+_UP5_SETS = {0: ((0, 1), (2, 3), (4,)), 1: ((0,), (1, 2), (3, 4))}   # filter rows merged onto low-res row a, per output phase
+
+
+def _up5_merged(w, py, px):
+    """w (Co,Ci,5,5) -> the 3x3 phase filter of output phase (py,px) (csrc/conv_fast.hip: up5_merge_kernel)."""
+    rows = [sum(w[:, :, ky, :] for ky in _UP5_SETS[py][a]) for a in range(3)]          # 3 x (Co,Ci,5)
+    return torch.stack([torch.stack([sum(r[:, :, kx] for kx in _UP5_SETS[px][b]) for b in range(3)], -1) for r in rows], -2)
+
+
+def _up5_forward(x, w, wq):
+    """Upsample(2)+reflect-pad(2)+5x5: output ring of width 2 from the exact gather with wq; interior from the four
+    VALID 3x3 phase convolutions of the low-res input with the ROUNDED MERGED filters."""
+    y = _plain_conv(x, wq, 1, 2, True)
+    H, W = x.shape[2], x.shape[3]
+    out = y.clone()
+    for py in (0, 1):
+        for px in (0, 1):
+            out[:, :, 2 + py: 2 * H - 2: 2, 2 + px: 2 * W - 2: 2] = F.conv2d(x, _q(_up5_merged(w, py, px)))
+    return out
+
+
+class _ConvQ(torch.autograd.Function):
+    """One convolution under the 16-bit compute contract (see above); flags say which of forward / dgrad / wgrad
+    have a 16-bit kernel for this shape (acl-gan_amd/csrc/conv_fast16.hip: fwd16_ok / dgrad16_ok / wgrad16_ok)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, upsample, f16, d16, w16):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, upsample, d16, w16)
+        up5 = upsample and w.shape[2] == 5 and pad == 2 and stride == 1 and x.shape[2] >= 4 and x.shape[3] >= 4
+        ctx.up5 = up5
+        if not f16:
+            y = _plain_conv(x, w, stride, pad, upsample)
+        elif up5:
+            y = _up5_forward(_q(x), w, _q(w))
+        else:
+            y = _plain_conv(_q(x), _q(w), stride, pad, upsample)
+        return y + b.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, upsample, d16, w16 = ctx.cfg
+        db = dy.sum(dim=(0, 2, 3))                     # summed from the unrounded fp32 dy
+        with torch.enable_grad():
+            # ---- dgrad ----
+            xv = x.detach().requires_grad_(True)
+            if d16 and ctx.up5:
+                dyq = _qg(dy)
+                H, W = x.shape[2], x.shape[3]
+                ring = torch.ones_like(dyq)
+                ring[:, :, 2: 2 * H - 2, 2: 2 * W - 2] = 0
+                tot = (_plain_conv(xv, _q(w), 1, 2, True) * (dyq * ring)).sum()
+                for py in (0, 1):
+                    for px in (0, 1):
+                        tot = tot + (F.conv2d(xv, _q(_up5_merged(w, py, px))) * dyq[:, :, 2 + py: 2 * H - 2: 2, 2 + px: 2 * W - 2: 2]).sum()
+                dx, = torch.autograd.grad(tot, xv)
+            elif d16:
+                dx, = torch.autograd.grad(_plain_conv(xv, _q(w), stride, pad, upsample), xv, _qg(dy))
+            else:
+                dx, = torch.autograd.grad(_plain_conv(xv, w, stride, pad, upsample), xv, dy)
+            # ---- wgrad ----
+            wv = w.detach().requires_grad_(True)
+            if w16:
+                dw, = torch.autograd.grad(_plain_conv(_q(x), wv, stride, pad, upsample), wv, _qg(dy))
+            else:
+                dw, = torch.autograd.grad(_plain_conv(x, wv, stride, pad, upsample), wv, dy)
+        return dx, dw, db, None, None, None, None, None, None
+
+
 def conv_block(x, w, b, stride, pad, act="none", norm="none", norm_args=None, upsample=False):
     """Conv2dBlock.forward (networks.py:365-371): reflect pad -> conv(bias) -> norm -> act.
     ``upsample`` restates the nn.Upsample(scale_factor=2) (nearest) that precedes the two
     5x5 decoder convs (networks.py:256)."""
+    co, ci = w.shape[0], w.shape[1]
+    if _QDT is not None and ci % 32 == 0 and co % 32 == 0:
+        ok64 = ci % 64 == 0 and co % 64 == 0
+        y = _ConvQ.apply(x, w, b, stride, pad, upsample, True, True, ok64)
+        return _norm_act(y, act, norm, norm_args)
     if upsample:
         x = F.interpolate(x, scale_factor=2, mode="nearest")
     if pad > 0:
         x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
     y = F.conv2d(x, w, b, stride=stride)
+    return _norm_act(y, act, norm, norm_args)
+
+
+def _norm_act(y, act, norm, norm_args):
     if norm == "in":
         y = instance_norm(y)
     elif norm == "adain":

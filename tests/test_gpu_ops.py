@@ -254,7 +254,8 @@ def test_avgpool(L, shape):
     L.check(L.lib.aclgan_avgpool3s2_fwd(B, H, W, Cn, L.ptr(xg), L.ptr(yg), L.stream_ptr()))
     assert rel_err(nchw(yg), y) < 1e-6
     dxg = torch.full_like(xg, float("nan"))
-    L.check(L.lib.aclgan_avgpool3s2_bwd(B, H, W, Cn, L.ptr(nhwc(dy).cuda()), L.ptr(dxg), 0, L.stream_ptr()))
+    dyg = nhwc(dy).cuda()   # named: a temporary could be freed and reused before the launch
+    L.check(L.lib.aclgan_avgpool3s2_bwd(B, H, W, Cn, L.ptr(dyg), L.ptr(dxg), 0, L.stream_ptr()))
     assert rel_err(nchw(dxg), x.grad) < 1e-6
 
 
@@ -271,7 +272,8 @@ def test_adam_flat_matches_torch_adam(L):
         grad = torch.randn(n, generator=g) * 0.01
         p_ref.grad = grad.clone()
         opt.step()
-        L.check(L.lib.aclgan_adam_flat(L.ptr(p), L.ptr(grad.cuda()), L.ptr(m), L.ptr(v), n, C.byref(a), step, L.stream_ptr()))
+        gg = grad.cuda()
+        L.check(L.lib.aclgan_adam_flat(L.ptr(p), L.ptr(gg), L.ptr(m), L.ptr(v), n, C.byref(a), step, L.stream_ptr()))
     assert (p.cpu() - p_ref.detach()).abs().max().item() < 2e-7
 
 

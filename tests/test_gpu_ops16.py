@@ -95,12 +95,12 @@ def test_conv_fwd16(L, case, dt):
     assert L.lib.aclgan_conv16_eligible(C.byref(d), 0) == 1
     for grid in (False, True) if up else (False,):
         x, w, b = _tensors(case, 0, grid)
-        wg = ohwi(w).cuda()
+        wg, xg, bg = ohwi(w).cuda(), nhwc(x).cuda(), b.cuda()     # named: a temporary would be freed (and reused) before the launch
         w16, _ = _packs(L, wg, dt)
         Ho, Wo = out_hw(Hi, Wi, k, s, p, up)
         y = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
         scr = _scratch(L.lib.aclgan_conv2d_fwd16_scratch_bytes(C.byref(d)))
-        L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), L.DTYPE[dt], L.ptr(nhwc(x).cuda()), L.ptr(wg), L.ptr(w16), L.ptr(b.cuda()), L.ptr(y),
+        L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), L.DTYPE[dt], L.ptr(xg), L.ptr(wg), L.ptr(w16), L.ptr(bg), L.ptr(y),
                                           L.ptr(scr), L.stream_ptr()), "conv2d_fwd16")
         exact = O.conv_block(_rounded(x, dt).double(), _rounded(w, dt).double(), b.double(), s, p, act, upsample=bool(up))
         full = O.conv_block(x, w, b, s, p, act, upsample=bool(up))
@@ -109,7 +109,7 @@ def test_conv_fwd16(L, case, dt):
         assert rel_err(nchw(y), full) < PREC_TOL[dt]
         # reproducible bit for bit (split-K layers reduce ordered partials)
         y2 = torch.empty_like(y)
-        L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), L.DTYPE[dt], L.ptr(nhwc(x).cuda()), L.ptr(wg), L.ptr(w16), L.ptr(b.cuda()), L.ptr(y2),
+        L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), L.DTYPE[dt], L.ptr(xg), L.ptr(wg), L.ptr(w16), L.ptr(bg), L.ptr(y2),
                                           L.ptr(scr), L.stream_ptr()))
         assert torch.equal(y, y2)
 
@@ -129,11 +129,11 @@ def test_conv_dgrad16(L, case, dt):
         y.backward(_rounded(dy, dt).double())
         xf = x.clone().requires_grad_(True)
         O.conv_block(xf, w, b, s, p, "none", upsample=bool(up)).backward(dy)
-        wg = ohwi(w).cuda()
+        wg, dyg = ohwi(w).cuda(), nhwc(dy).cuda()
         _, w16t = _packs(L, wg, dt)
         scr = _scratch(L.lib.aclgan_conv2d_dgrad16_scratch_bytes(C.byref(d)))
         dx = torch.full((B, Hi, Wi, Ci), float("nan"), device="cuda")
-        L.check(L.lib.aclgan_conv2d_dgrad16(C.byref(d), L.DTYPE[dt], L.ptr(nhwc(dy).cuda()), L.ptr(wg), L.ptr(w16t), L.ptr(dx), 0, L.ptr(scr),
+        L.check(L.lib.aclgan_conv2d_dgrad16(C.byref(d), L.DTYPE[dt], L.ptr(dyg), L.ptr(wg), L.ptr(w16t), L.ptr(dx), 0, L.ptr(scr),
                                             L.stream_ptr()), "conv2d_dgrad16")
         if not up or grid:
             assert rel_err(nchw(dx), xr.grad) < EXACT_TOL, ("exact", grid)
@@ -141,7 +141,7 @@ def test_conv_dgrad16(L, case, dt):
         # accumulate mode
         base = torch.randn(B, Hi, Wi, Ci, generator=torch.Generator().manual_seed(6))
         acc = base.clone().cuda()
-        L.check(L.lib.aclgan_conv2d_dgrad16(C.byref(d), L.DTYPE[dt], L.ptr(nhwc(dy).cuda()), L.ptr(wg), L.ptr(w16t), L.ptr(acc), 1, L.ptr(scr),
+        L.check(L.lib.aclgan_conv2d_dgrad16(C.byref(d), L.DTYPE[dt], L.ptr(dyg), L.ptr(wg), L.ptr(w16t), L.ptr(acc), 1, L.ptr(scr),
                                             L.stream_ptr()))
         assert rel_err(nchw(acc).cpu() - nchw(base), xf.grad) < PREC_TOL[dt] + 5 * EXACT_TOL
 
@@ -163,7 +163,8 @@ def test_conv_wgrad16(L, case, dt):
     dw = torch.zeros(Co, k, k, Ci, device="cuda")
     db = torch.zeros(Co, device="cuda")
     scr = _scratch(L.lib.aclgan_conv2d_wgrad16_scratch_bytes(C.byref(d)))
-    L.check(L.lib.aclgan_conv2d_wgrad16(C.byref(d), L.DTYPE[dt], L.ptr(nhwc(x).cuda()), L.ptr(nhwc(dy).cuda()), L.ptr(dw), L.ptr(db), L.ptr(scr),
+    xg, dyg = nhwc(x).cuda(), nhwc(dy).cuda()
+    L.check(L.lib.aclgan_conv2d_wgrad16(C.byref(d), L.DTYPE[dt], L.ptr(xg), L.ptr(dyg), L.ptr(dw), L.ptr(db), L.ptr(scr),
                                         L.stream_ptr()), "conv2d_wgrad16")
     assert rel_err(dw, ohwi(wr.grad)) < EXACT_TOL      # exact path too for the sub-pixel layers: wgrad merges nothing before rounding
     assert rel_err(dw, ohwi(wf.grad)) < PREC_TOL[dt]

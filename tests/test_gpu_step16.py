@@ -1,12 +1,25 @@
 """BASELINE.json configs[2] (bf16) and configs[4] (fp16 + loss scaling): the training step with the heavy convolutions
-on the 16-bit matrix cores, against the fp32 CPU oracle.
+on the 16-bit matrix cores.
 
-The reference is fp32-only, so there is no reference behaviour to match bit for bit; the contract is a STATED tolerance
-against the fp32 oracle on identical weights / inputs / z (kernel-level exactness is tests/test_gpu_ops16.py):
+The reference is fp32-only, so there is no reference behaviour to match bit for bit.  Two checks, same weights / inputs / z:
 
-                          forward tensors   losses   gradients (per-tensor relative L2, smooth fixture)
-    bf16  (8-bit mantissa)     3e-2          2e-2        1e-1
-    fp16  (11-bit mantissa)    4e-3          3e-3        2e-2
+  (1) against the EMULATED CONTRACT: oracle/aclgan_oracle.py::compute_dtype restates, on the CPU, exactly what the 16-bit
+      path promises (both GEMM operands of every eligible convolution rounded to the 16-bit type, fp32 accumulation,
+      merged phase filters rounded in the sub-pixel layers, gradients rounded at the loss scale they carry, everything
+      else fp32).  Two implementations of the SAME contract still drift apart: a pre-rounding difference of 1e-7 (fp32
+      summation order) flips the 16-bit rounding of a few values, each flip is a 2^-9 (2^-12) relative kick, and after a
+      handful of layers every value carries quantisation-level noise -- so deep tensors agree with the emulation only
+      ~1.5x better than with the fp32 oracle, while shallow ones (style code s_2: five convolutions) agree ~30x better:
+      s_2 <= 5e-4 / 1e-4 is the sharp step-level check; kernel-level exactness is tests/test_gpu_ops16.py (2e-4).
+  (2) against the fp32 ORACLE: the stated precision of the reduced-precision configs,
+
+                              forward tensors   losses (adv, idt, totals | focus digit | focus size)   gradients (per-tensor
+        bf16  (8-bit mantissa)     6e-2          1e-3 | 1.5e-2 | 6e-2                                   relative L2, smooth
+        fp16  (11-bit mantissa)    8e-3          1e-4 | 6e-4   | 1.5e-2                                 fixture)  3e-1 / 1.2e-1
+
+      The gradient figures are a property of the contract, not of the kernels: the CPU emulation sits at the same
+      distance from the fp32 oracle (0.226 for bf16 on the worst tensor, gen_AB enc_content.model.1.conv.weight --
+      ReLU masks of ~25 stacked layers flip when activations move by 2^-9).
 
 fp16 runs under dynamic loss scaling: gradient buffers carry S*g, Adam divides by S on the device, an overflowing
 update is skipped and halves S -- both behaviours are tested.
@@ -21,9 +34,15 @@ from oracle import aclgan_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-FTOL = {"bf16": 3e-2, "fp16": 4e-3}
-LTOL = {"bf16": 2e-2, "fp16": 3e-3}
-GTOL = {"bf16": 1e-1, "fp16": 2e-2}
+FTOL = {"bf16": 6e-2, "fp16": 8e-3}
+LTOL = {"bf16": 1e-3, "fp16": 1e-4}         # adversarial / identity / total losses (measured worst 2.1e-4 / 1.5e-5)
+LTOL_DIGIT = {"bf16": 1.5e-2, "fp16": 6e-4}   # sum 1/(|m-.5|+0.01): ill-conditioned in the mask values (measured 7.5e-3 / 2.9e-4)
+LTOL_SIZE = {"bf16": 6e-2, "fp16": 1.5e-2}    # relu(sum(m - upper))^2 near its threshold (measured 3.2e-2 / 8.1e-3)
+GTOL = {"bf16": 3e-1, "fp16": 1.2e-1}
+ETOL_F = {"bf16": 5e-2, "fp16": 6e-3}      # vs the emulated contract (measured worst 3.6e-2 / 4.0e-3, x_A2_fake)
+ETOL_S2 = {"bf16": 5e-4, "fp16": 1e-4}     # the shallow tensor s_2 vs the emulated contract (measured 1.3e-4 / 4.3e-5)
+ETOL_G = {"bf16": 2.5e-1, "fp16": 1e-1}    # measured worst 1.67e-1 / 6.3e-2
+SCALE = {"bf16": 1.0, "fp16": 65536.0}
 
 
 @pytest.fixture(scope="module")
@@ -67,25 +86,36 @@ def test_forward_and_losses_16bit(T, dt, B, S):
         _, Lg, fw = O.gen_losses(nets, x_a, x_b, z[3:], cfg)
         _, Ld, _ = O.dis_losses(nets, x_a, x_b, z[:3], cfg)
         dA = O.dis_forward(nets["dis_A"], fw["x_A_fake"], cfg["dis"])
+        with O.compute_dtype(dt):
+            _, _, fe = O.gen_losses(nets, x_a, x_b, z[3:], cfg)
+            dAe = O.dis_forward(nets["dis_A"], fe["x_A_fake"], cfg["dis"])
     xa = x_a.cuda()
     zz = [t.cuda() for t in z[3:]]
-    worst = {}
-    c1, _ = tr.gen_AB.encode(xa); worst["c_1"] = _rel(c1, fw["c_1"])
-    c2, s2 = tr.gen_BA.encode(xa); worst["c_2"] = _rel(c2, fw["c_2"]); worst["s_2"] = _rel(s2, fw["s_2"])
+    worst, worst_e = {}, {}
+
+    def chk(name, got, key=None):
+        worst[name] = _rel(got, fw[key or name]); worst_e[name] = _rel(got, fe[key or name])
+
+    c1, _ = tr.gen_AB.encode(xa); chk("c_1", c1)
+    c2, s2 = tr.gen_BA.encode(xa); chk("c_2", c2); chk("s_2", s2)
     xB4 = tr.gen_AB.decode(c1, zz[0])
-    xB = tr.focus_translation(xB4[:, :3], xa, xB4[:, 3:]); worst["x_B_fake"] = _rel(xB, fw["x_B_fake"])
-    worst["f_B"] = _rel(xB4[:, 3:], fw["f_B"])
-    rec = tr.gen_BA.decode(c2, s2); worst["x_A_recon"] = _rel(rec[:, :3], fw["x_A_recon"])
-    c3, _ = tr.gen_BA.encode(xB); worst["c_3"] = _rel(c3, fw["c_3"])
+    xB = tr.focus_translation(xB4[:, :3], xa, xB4[:, 3:]); chk("x_B_fake", xB)
+    chk("f_B", xB4[:, 3:])
+    rec = tr.gen_BA.decode(c2, s2); chk("x_A_recon", rec[:, :3])
+    c3, _ = tr.gen_BA.encode(xB); chk("c_3", c3)
     xA24 = tr.gen_BA.decode(c3, zz[2])
-    xA2 = tr.focus_translation(xA24[:, :3], xB, xA24[:, 3:]); worst["x_A2_fake"] = _rel(xA2, fw["x_A2_fake"])
+    xA2 = tr.focus_translation(xA24[:, :3], xB, xA24[:, 3:]); chk("x_A2_fake", xA2)
     xA4 = tr.gen_BA.decode(c2, cfg["alpha"] * zz[1])
     xA = tr.focus_translation(xA4[:, :3], xa, xA4[:, 3:])
-    for s, (g_, w_) in enumerate(zip(tr.dis_A(xA), dA)):
-        worst["dis_A_xA_s%d" % s] = _rel(g_, w_)
-    print("%s forward max-abs rel errors @%dx%d B=%d:" % (dt, S, S, B), {k: "%.2e" % v for k, v in worst.items()})
+    for s, (g_, w_, e_) in enumerate(zip(tr.dis_A(xA), dA, dAe)):
+        worst["dis_A_xA_s%d" % s] = _rel(g_, w_); worst_e["dis_A_xA_s%d" % s] = _rel(g_, e_)
+    print("%s forward max-abs rel errors vs fp32 oracle @%dx%d B=%d:" % (dt, S, S, B), {k: "%.2e" % v for k, v in worst.items()})
+    print("%s forward max-abs rel errors vs emulated contract:" % dt, {k: "%.2e" % v for k, v in worst_e.items()})
     bad = {k: v for k, v in worst.items() if not v < FTOL[dt]}
     assert not bad, bad
+    bad = {k: v for k, v in worst_e.items() if not v < ETOL_F[dt]}
+    assert not bad, ("emulated", bad)
+    assert worst_e["s_2"] < ETOL_S2[dt], ("emulated s_2", worst_e["s_2"])
     tr.dis_update(x_a, x_b, cfg, z=z[:3])
     ld = {n: float(getattr(tr, n)) for n in Ld}
     tr2 = _make(T, cfg, nets, dt)
@@ -95,9 +125,7 @@ def test_forward_and_losses_16bit(T, dt, B, S):
     for n, v in list(Ld.items()) + list(Lg.items()):
         v = float(v)
         got = ld[n] if n in ld else lg[n]
-        # 'size' losses square a sum that sits near its relu threshold; 'digit' sums 1/(|m-.5|+0.01): both are ill-conditioned
-        # in the mask values themselves (tests/golden/make_golden.py) -> 5x the plain tolerance
-        tol = LTOL[dt] * (5 if ("_size" in n or "_digit" in n or n == "loss_gen_total") else 1)
+        tol = LTOL_SIZE[dt] if "_size" in n else (LTOL_DIGIT[dt] if "_digit" in n else LTOL[dt])
         errs[n] = (abs(got - v) / max(1e-3, abs(v)), tol, got, v)
     print("%s loss rel errors:" % dt, {k: "%.2e" % e[0] for k, e in errs.items()})
     bad = {k: e for k, e in errs.items() if not e[0] <= e[1]}
@@ -116,17 +144,22 @@ def test_step_gradients_16bit(T, dt):
     assert (sd == 65536.0 and sg == 65536.0) if dt == "fp16" else (sd == 1.0 and sg == 1.0)
     od = O.OracleTrainer(cfg, nets=nets); od.dis_update(x_a, x_b, z[:3], apply=False)
     og = O.OracleTrainer(cfg, nets=nets); og.gen_update(x_a, x_b, z[3:], apply=False)
-    worst = []
-    for tr, orc, nets_, S in ((trd, od, ("dis_A", "dis_B", "dis_2"), sd), (trg, og, ("gen_AB", "gen_BA"), sg)):
+    with O.compute_dtype(dt, loss_scale=SCALE[dt]):
+        ed = O.OracleTrainer(cfg, nets=nets); ed.dis_update(x_a, x_b, z[:3], apply=False)
+        eg = O.OracleTrainer(cfg, nets=nets); eg.gen_update(x_a, x_b, z[3:], apply=False)
+    worst, worst_e = [], []
+    for tr, orc, emu, nets_, S in ((trd, od, ed, ("dis_A", "dis_B", "dis_2"), sd), (trg, og, eg, ("gen_AB", "gen_BA"), sg)):
         gmax = max(float(t.grad.norm()) for n in nets_ for t in orc.nets[n].values())
         for n in nets_:
             for k, gr in getattr(tr, n).named_grads():
-                ref = orc.nets[n][k].grad.double()
-                err = (gr.cpu().double() / S - ref).norm().item()
-                worst.append((err / (ref.norm().item() + 1e-4 * gmax), n, k))
-    worst.sort(reverse=True)
-    print("%s worst gradient tensors (relative L2):" % dt, [("%.2e" % e, n, k) for e, n, k in worst[:6]])
+                got = gr.cpu().double() / S
+                for lst, ref in ((worst, orc.nets[n][k].grad.double()), (worst_e, emu.nets[n][k].grad.double())):
+                    lst.append(((got - ref).norm().item() / (ref.norm().item() + 1e-4 * gmax), n, k))
+    worst.sort(reverse=True); worst_e.sort(reverse=True)
+    print("%s worst gradient tensors vs fp32 oracle (relative L2):" % dt, [("%.2e" % e, n, k) for e, n, k in worst[:6]])
+    print("%s worst gradient tensors vs emulated contract:" % dt, [("%.2e" % e, n, k) for e, n, k in worst_e[:6]])
     assert worst[0][0] <= GTOL[dt], worst[:6]
+    assert worst_e[0][0] <= ETOL_G[dt], ("emulated", worst_e[:6])
     if dt == "fp16":
         st = trg.loss_scale_state()
         assert st["skipped_gen"] == 0 and st["clean_updates"] == 1 and st["scale"] == 65536.0
@@ -185,7 +218,7 @@ def test_full_size_step_properties_16bit(T, dt):
     torch.cuda.synchronize()
     for n in ["loss_gen_adv_A", "loss_gen_adv_B", "loss_gen_adv_2", "loss_idt_A", "loss_idt_B"]:
         a, b = float(getattr(tr, n)), float(getattr(tr32, n))
-        assert np.isfinite(a) and abs(a - b) <= LTOL[dt] * max(1e-3, abs(b)), (n, a, b)
+        assert np.isfinite(a) and abs(a - b) <= 10 * LTOL[dt] * max(1e-3, abs(b)), (n, a, b)
     assert torch.equal(tr._param[1], dis0)
     d = (tr._param[0] - gen0).abs().max().item()
     assert 0 < d <= 1.01 * cfg["lr"]
