@@ -112,6 +112,17 @@ SIGNATURES = {
     "aclgan_avgpool3s2_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp]),
     "aclgan_avgpool3s2_bwd": (ci, [ci, ci, ci, ci, vp, vp, ci, vp]),
     "aclgan_adam_flat": (ci, [vp, vp, vp, vp, i64, C.POINTER(Adam), ci, vp]),
+    "aclgan_linear_fwd": (ci, [ci, ci, ci, vp, vp, vp, ci, vp, vp]),
+    "aclgan_linear_bwd": (ci, [ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+    "aclgan_gap_fwd": (ci, [ci, ci, ci, vp, vp, vp]),
+    "aclgan_gap_bwd": (ci, [ci, ci, ci, vp, vp, ci, vp]),
+    "aclgan_focus_blend_fwd": (ci, [ci, ci, vp, vp, vp, vp, vp, vp]),
+    "aclgan_focus_blend_bwd": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "aclgan_focus_translation_nchw": (ci, [vp, i64, vp, i64, vp, i64, vp, ci, ci, vp]),
+    "aclgan_lsgan_loss": (ci, [vp, ci, cf, cf, vp, vp, cf, vp]),
+    "aclgan_l1_loss": (ci, [vp, ci, vp, i64, vp, vp, cf, ci, vp]),
+    "aclgan_focus_loss_scratch_bytes": (sz, [i64]),
+    "aclgan_focus_loss": (ci, [vp, i64, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp]),
     "aclgan_nchw_to_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "aclgan_nhwc_to_nchw": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "aclgan_image_resample_ksize": (ci, [ci, ci]),

@@ -138,6 +138,56 @@ int aclgan_conv2d_wgrad16(const aclgan_conv_desc* d, int dtype, const float* x, 
     return rc;
 }
 
+// ---- small dense layers, pooling, blend and loss operators (the step is built from exactly these launchers) ----
+int aclgan_linear_fwd(int B, int I, int O, const float* x, const float* w, const float* bias, int act, float* y, void* stream) {
+    ACL_REQUIRE(B > 0 && I > 0 && O > 0 && x && w && y, "linear_fwd: bad arguments");
+    return linear_fwd(B, I, O, x, w, bias, act, y, (hipStream_t)stream);
+}
+int aclgan_linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, const float* w, int act, float* dx, float* dw, float* db,
+                      void* stream) {
+    ACL_REQUIRE(B > 0 && I > 0 && O > 0 && x && y && dy && w, "linear_bwd: bad arguments");
+    return linear_bwd(B, I, O, x, y, dy, w, act, dx, dw, db, (hipStream_t)stream);
+}
+int aclgan_gap_fwd(int B, int HW, int C, const float* x, float* y, void* stream) {
+    ACL_REQUIRE(B > 0 && HW > 0 && C > 0 && x && y, "gap_fwd: bad arguments");
+    return gap_fwd(B, HW, C, x, y, (hipStream_t)stream);
+}
+int aclgan_gap_bwd(int B, int HW, int C, const float* dy, float* dx, int accumulate, void* stream) {
+    ACL_REQUIRE(B > 0 && HW > 0 && C > 0 && dy && dx, "gap_bwd: bad arguments");
+    return gap_bwd(B, HW, C, dy, dx, accumulate, (hipStream_t)stream);
+}
+int aclgan_focus_blend_fwd(int B, int HW, const float* dec4, const float* bg, float* out, const float* pair_first, float* pair, void* stream) {
+    ACL_REQUIRE(B > 0 && HW > 0 && dec4 && bg && out && (!pair == !pair_first), "focus_blend_fwd: bad arguments");
+    return focus_blend_fwd(B, HW, dec4, bg, out, pair_first, pair, (hipStream_t)stream);
+}
+int aclgan_focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const float* d_out, const float* d_pair, float* d_dec4, float* d_bg,
+                           int bg_accumulate, void* stream) {
+    ACL_REQUIRE(B > 0 && HW > 0 && dec4 && bg && d_dec4 && (d_out || d_pair), "focus_blend_bwd: bad arguments");
+    return focus_blend_bwd(B, HW, dec4, bg, d_out, d_pair, d_dec4, d_bg, bg_accumulate, (hipStream_t)stream);
+}
+int aclgan_focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg, int64_t bg_bstride, const float* focus, int64_t focus_bstride,
+                                  float* out, int B, int HW, void* stream) {
+    ACL_REQUIRE(B > 0 && HW > 0 && fg && bg && focus && out, "focus_translation_nchw: bad arguments");
+    return focus_translation_nchw(fg, fg_bstride, bg, bg_bstride, focus, focus_bstride, out, B, HW, (hipStream_t)stream);
+}
+int aclgan_lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, void* stream) {
+    ACL_REQUIRE(o && n > 0 && loss_slot, "lsgan_loss: bad arguments");
+    return lsgan_loss(o, n, target, weight, loss_slot, d_o, gscale, (hipStream_t)stream);
+}
+int aclgan_l1_loss(const float* a, int a_channels, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate,
+                   void* stream) {
+    ACL_REQUIRE(a && b && npix > 0 && loss_slot && (a_channels == 3 || a_channels == 4), "l1_loss: bad arguments (a has 3 or 4 channels)");
+    return l1_loss(a, a_channels, b, npix, loss_slot, d_a, gscale, d_accumulate, (hipStream_t)stream);
+}
+size_t aclgan_focus_loss_scratch_bytes(int64_t npix) { return npix > 0 ? (size_t)2 * focus_sums_blocks(npix) * sizeof(float) : 0; }
+int aclgan_focus_loss(const float* dec4, int64_t npix, float delta, float upper, float lower, float eps, float scale, float* size_slot,
+                      float* digit_slot, float* d_dec4, void* scratch, void* stream) {
+    ACL_REQUIRE(dec4 && npix > 0 && size_slot && digit_slot && scratch, "focus_loss: bad arguments");
+    const int rc = focus_sums(dec4, npix, eps, upper, (float*)scratch, (hipStream_t)stream);
+    if (rc) return rc;
+    return focus_loss_finish(dec4, npix, (const float*)scratch, delta, upper, lower, eps, scale, size_slot, digit_slot, d_dec4, (hipStream_t)stream);
+}
+
 size_t aclgan_norm_scratch_bytes(int B, int HW, int C) { return norm_scratch_bytes(B, HW, C); }
 int aclgan_norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const float* w, const float* b, int w_stride,
                     const float* residual, float* y, float* mean, float* rstd, void* scratch, void* stream) {

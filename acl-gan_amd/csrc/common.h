@@ -109,6 +109,10 @@ int focus_blend_fwd(int B, int HW, const float* dec4, const float* bg, float* ou
 // caller), d_bg (+= if accumulate else =; may be null)
 int focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const float* d_out, const float* d_pair,
                     float* d_dec4, float* d_bg, int bg_accumulate, hipStream_t st);
+// focus_translation on the reference's own NCHW tensors (sample() / test.py: trainer.py:85-88, test.py:73-76):
+// out[b][c][p] = fg[b][c][p]*m + bg[b][c][p]*(1-m), m = (focus[b][0][p]+1)/2, c < 3; *_bstride = floats between samples
+int focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg, int64_t bg_bstride, const float* focus, int64_t focus_bstride,
+                           float* out, int B, int HW, hipStream_t st);
 // LSGAN (networks.py:67,83,98): loss_slot += weight*mean((o-t)^2); d_o = weight*2(o-t)/n*gscale (if d_o != null)
 // lscale (optional, device): fp16 dynamic loss scale; the gradient seed is multiplied by lscale[0], the reported loss is not
 int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st, const float* lscale = nullptr);

@@ -31,9 +31,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 8 packed 16
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BK16 = 32;        // k values per tile
-constexpr int LDQ = 5;          // LDS row stride in u32x4 units: 4 chunks of 8 halfs + 1 pad = 80 bytes
-constexpr int WG16_MAX_CHUNK = 1024 + BK16;
+constexpr int BK16 = 32;        // k values per tile of the wgrad kernel (KS = 2) and the unit of the split-K plans
+constexpr int LDQ = 5;          // KS = 2: LDS row stride in u32x4 units: 4 chunks of 8 halfs + 1 pad = 80 bytes
+// forward / dgrad are templated on KS = k-steps (of 16) per tile: KS = 4 (64-deep tiles, row stride 9 x 16 = 144 bytes,
+// b128 rows still conflict-free: 36 dwords = 4 banks further per row) when the GEMM k axis allows it.  Why: at the 16-bit
+// MFMA rate a 32-deep tile is only 8 MFMAs = 256 cycles per wave, far less than one global-load latency, and the
+// write-after-barrier pipeline gives a load exactly one iteration to land -- the 32-deep loop is LATENCY-bound
+// (measured: 24 % MFMA utilisation, insensitive to the bytes per tile).  64-deep tiles double the bytes in flight and
+// halve the barriers per MFMA.
 
 struct PBF16 {
     typedef bf16x8 vec;
@@ -55,19 +60,19 @@ __device__ __forceinline__ u32x4 pack8(f32x4 lo, f32x4 hi) {
     return T::pack(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// One k-tile = two MFMA k-steps.  Fragment of 32-row tile t, k-step ks, lane (l31, kh): chunk ks*2+kh of row base+t*32+l31.
-template <int TN_>
-__device__ __forceinline__ void read_frags16(const u32x4* __restrict__ tile, int base, int lane, u32x4 (&f)[TN_][2]) {
+// Fragment of 32-row tile t, k-step ks, lane (l31, kh): chunk ks*2+kh of row base+t*32+l31 (row stride 2*KS+1 chunks).
+template <int KS, int TN_>
+__device__ __forceinline__ void read_frags16(const u32x4* __restrict__ tile, int base, int lane, u32x4 (&f)[TN_][KS]) {
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int t = 0; t < TN_; ++t) {
-        const u32x4* p = tile + (base + t * 32 + l31) * LDQ + kh;
-        f[t][0] = p[0];
-        f[t][1] = p[2];
+        const u32x4* p = tile + (base + t * 32 + l31) * (2 * KS + 1) + kh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) f[t][ks] = p[2 * ks];
     }
 }
-template <class T, int TM, int TN>
-__device__ __forceinline__ void mfma_step16(const u32x4 (&fa)[TM][2], const u32x4 (&fb)[TN][2], int ks, f32x16 (&acc)[TM][TN]) {
+template <class T, int KS, int TM, int TN>
+__device__ __forceinline__ void mfma_step16(const u32x4 (&fa)[TM][KS], const u32x4 (&fb)[TN][KS], int ks, f32x16 (&acc)[TM][TN]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -76,7 +81,7 @@ __device__ __forceinline__ void mfma_step16(const u32x4 (&fa)[TM][2], const u32x
 
 // Same write-after-barrier pipeline as ACL_GEMM_MAINLOOP (conv_fast.hip): `fetch(t)` issues the global loads of tile t
 // into the staging registers, `stage(buf, real)` converts them and writes LDS buffer `buf`.  Both unconditional.
-#define ACL_GEMM16_MAINLOOP(T_, TM_, TN_, KBEG_, NK_, AS_, BS_, ASTR_, BSTR_, AM_, BN_)                  \
+#define ACL_GEMM16_MAINLOOP(T_, KS_, TM_, TN_, KBEG_, NK_, AS_, BS_, ASTR_, BSTR_, AM_, BN_)             \
     do {                                                                                                 \
         const int nk__ = (NK_), kb__ = (KBEG_);                                                          \
         fetch(kb__);                                                                                     \
@@ -85,14 +90,14 @@ __device__ __forceinline__ void mfma_step16(const u32x4 (&fa)[TM][2], const u32x
         __syncthreads();                                                                                 \
         for (int kt = 0; kt < nk__; ++kt) {                                                              \
             const int cur = kt & 1;                                                                      \
-            u32x4 fa[TM_][2], fb[TN_][2];                                                                \
-            read_frags16<TM_>((AS_) + cur * (ASTR_), (AM_), lane, fa);                                   \
-            read_frags16<TN_>((BS_) + cur * (BSTR_), (BN_), lane, fb);                                   \
-            mfma_step16<T_, TM_, TN_>(fa, fb, 0, acc);                                                   \
+            u32x4 fa[TM_][KS_], fb[TN_][KS_];                                                            \
+            read_frags16<KS_, TM_>((AS_) + cur * (ASTR_), (AM_), lane, fa);                              \
+            read_frags16<KS_, TN_>((BS_) + cur * (BSTR_), (BN_), lane, fb);                              \
+            mfma_step16<T_, KS_, TM_, TN_>(fa, fb, 0, acc);                                              \
             stage(cur ^ 1, kt + 1 < nk__);                                                               \
             fetch(kb__ + min(kt + 2, nk__ - 1));                                                         \
             __builtin_amdgcn_sched_barrier(0x6);   /* only ALU may cross: the loads of tile kt+2 issue HERE */ \
-            mfma_step16<T_, TM_, TN_>(fa, fb, 1, acc);                                                   \
+            _Pragma("unroll") for (int ks__ = 1; ks__ < (KS_); ++ks__) mfma_step16<T_, KS_, TM_, TN_>(fa, fb, ks__, acc); \
             __syncthreads();                                                                             \
         }                                                                                                \
     } while (0)
@@ -100,10 +105,11 @@ __device__ __forceinline__ void mfma_step16(const u32x4 (&fa)[TM][2], const u32x
 // ------------------------------------------------------------------------------------------
 // forward (Cin % 32 == 0)
 // ------------------------------------------------------------------------------------------
-template <class T, int WM, int WN, int TM, int TN>
+template <class T, int KS, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-    constexpr int RP = NT / 4;                 // rows covered per pass (4 chunks of 8 k per 32-deep row)
+    constexpr int NCH = 2 * KS, LDQ = NCH + 1, BKT = 16 * KS;   // chunks (of 8 k) per row, row stride, k values per tile
+    constexpr int RP = NT / NCH;               // rows covered per pass
     constexpr int A_IT = BM / RP, B_IT = (BN + RP - 1) / RP;
     __shared__ u32x4 smem[2 * (BM + BN) * LDQ];
     __shared__ int ro[BM];                     // output pixel index of each tile row (-1: not stored)
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_map(blockIdx.x, p.nwg);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-    const int q = tid & 3, r0 = tid >> 2;
+    const int q = tid % NCH, r0 = tid / NCH;
     const int phase = p.phases ? (int)blockIdx.z : 0;
     const u16* wbase = p.w16 + (size_t)phase * p.Co * p.K;
 
@@ -137,7 +143,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) wo[i] = min(n0 + r0 + i * RP, p.Co - 1) * p.K + q * 8;
 
-    const int cpt = p.Ci >> 5;                 // k-tiles per tap
+    const int cpt = p.Ci / BKT;                // k-tiles per tap
     int aoff[A_IT];
     f32x4 ra[A_IT][2];
     u32x4 rb[B_IT];
@@ -157,12 +163,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
         }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const f32x4* s = reinterpret_cast<const f32x4*>(p.x + (size_t)aoff[i] + cc * 32);
+            const f32x4* s = reinterpret_cast<const f32x4*>(p.x + (size_t)aoff[i] + cc * BKT);
             ra[i][0] = s[0]; ra[i][1] = s[1];
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (BN % RP == 0 || r0 + i * RP < BN) rb[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)wo[i] + kt * 32);
+            if (BN % RP == 0 || r0 + i * RP < BN) rb[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)wo[i] + kt * BKT);
     };
     auto stage = [&](int buf, bool real) __attribute__((always_inline)) {
         u32x4* a = As + buf * BM * LDQ;
@@ -182,11 +188,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk_all = p.K / BK16;
+    const int nk_all = p.K / BKT;
     const int kbeg = p.phases ? 0 : blockIdx.z * p.nkz, nk = p.phases ? nk_all : min(p.nkz, nk_all - kbeg);
     if (nk <= 0) return;
     const bool split = !p.phases && gridDim.z > 1;
-    ACL_GEMM16_MAINLOOP(T, TM, TN, kbeg, nk, As, Bs, BM * LDQ, BN * LDQ, wm * TM * 32, wn * TN * 32);
+    ACL_GEMM16_MAINLOOP(T, KS, TM, TN, kbeg, nk, As, Bs, BM * LDQ, BN * LDQ, wm * TM * 32, wn * TN * 32);
 
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -209,22 +215,22 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
     }
 }
 
-template <class T, int WM, int WN, int TM, int TN>
+template <class T, int KS, int WM, int WN, int TM, int TN>
 int launch_fwd16(const ConvGeom& g, FwdFP p, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BKT = 16 * KS;
     p.tiles_n = cdiv(g.Co, BN);
     const int rows = p.ring > 0 ? p.B * (p.Ho * p.Wo - std::max(0, p.Ho - 2 * p.ring) * std::max(0, p.Wo - 2 * p.ring)) : p.M;
     p.nwg = cdiv(rows, BM) * p.tiles_n;
     if (p.phases) {
-        hipLaunchKernelGGL((conv_fwd16_kernel<T, WM, WN, TM, TN>), dim3(p.nwg, 1, 4), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN>), dim3(p.nwg, 1, 4), dim3(WM * WN * 64), 0, st, p);
         ACL_CHECK_LAUNCH("conv_fwd16_kernel(phases)");
         return ACLGAN_OK;
     }
     int splits = 1;
-    fwd_split_plan(rows, g.Co, g.K, BK16, &splits, &p.nkz);
+    fwd_split_plan(rows, g.Co, g.K, BKT, &splits, &p.nkz);
     p.rows = rows;
-    if (splits > 1 && p.part == nullptr) { splits = 1; p.nkz = g.K / BK16; }   // no partial buffer: single pass (never atomics)
-    hipLaunchKernelGGL((conv_fwd16_kernel<T, WM, WN, TM, TN>), dim3(p.nwg, 1, splits), dim3(WM * WN * 64), 0, st, p);
+    if (splits > 1 && p.part == nullptr) { splits = 1; p.nkz = g.K / BKT; }   // no partial buffer: single pass (never atomics)
+    hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN>), dim3(p.nwg, 1, splits), dim3(WM * WN * 64), 0, st, p);
     ACL_CHECK_LAUNCH("conv_fwd16_kernel");
     if (splits > 1) {
         hipLaunchKernelGGL(fwd_split_finish_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)rows * std::max(1, g.Co / 4), 256), 4096)), dim3(256), 0, st, p, splits);
@@ -236,10 +242,11 @@ int launch_fwd16(const ConvGeom& g, FwdFP p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // dgrad (Cout % 32 == 0, Cin % 32 == 0): interior rows straight into dx, halo ring mirrored in with atomics
 // ------------------------------------------------------------------------------------------
-template <class T, int WM, int WN, int TM, int TN>
+template <class T, int KS, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-    constexpr int RP = NT / 4;
+    constexpr int NCH = 2 * KS, LDQ = NCH + 1, BKT = 16 * KS;
+    constexpr int RP = NT / NCH;
     constexpr int A_IT = BM / RP, B_IT = (BN + RP - 1) / RP;
     __shared__ u32x4 smem[2 * (BM + BN) * LDQ];
     __shared__ int ri_o[BM];
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
     const int cls = blockIdx.z / p.ksplit, slice = blockIdx.z - cls * p.ksplit;
     const int cy = cls / p.s, cx = cls % p.s;
     const int Tx = (p.k - cx + p.s - 1) / p.s, Ty = (p.k - cy + p.s - 1) / p.s;
-    const int q = tid & 3, r0 = tid >> 2;
+    const int q = tid % NCH, r0 = tid / NCH;
 
     int ylo, yhi, xlo, xhi;
     dg_box(p, cy, cx, ylo, yhi, xlo, xhi);
@@ -279,7 +286,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
     int bo[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) bo[i] = min(n0 + r0 + i * RP, p.Ci - 1) * p.Co + q * 8;
-    const int cpt = p.Co >> 5;
+    const int cpt = p.Co / BKT;
     int aoff[A_IT];
     f32x4 ra[A_IT][2];
     u32x4 rb[B_IT];
@@ -305,13 +312,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
         }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const f32x4* s = reinterpret_cast<const f32x4*>(p.dy + (size_t)(aoff[i] < 0 ? 0 : aoff[i]) + cc * 32);
+            const f32x4* s = reinterpret_cast<const f32x4*>(p.dy + (size_t)(aoff[i] < 0 ? 0 : aoff[i]) + cc * BKT);
             ra[i][0] = s[0]; ra[i][1] = s[1];
             za[i] = aoff[i] < 0 ? 0.f : 1.f;       // applied in stage(): keeps the loads a full tile ahead of their first use
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (BN % RP == 0 || r0 + i * RP < BN) rb[i] = *reinterpret_cast<const u32x4*>(p.w16t + (size_t)tapoff + bo[i] + cc * 32);
+            if (BN % RP == 0 || r0 + i * RP < BN) rb[i] = *reinterpret_cast<const u32x4*>(p.w16t + (size_t)tapoff + bo[i] + cc * BKT);
     };
     auto stage = [&](int buf, bool real) __attribute__((always_inline)) {
         u32x4* a = As + buf * BM * LDQ;
@@ -335,7 +342,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
     const int nkz = (nk_all + p.ksplit - 1) / p.ksplit;
     const int kbeg = slice * nkz, nk = min(nkz, nk_all - kbeg);
     if (nk <= 0) return;
-    ACL_GEMM16_MAINLOOP(T, TM, TN, kbeg, nk, As, Bs, BM * LDQ, BN * LDQ, wm * TM * 32, wn * TN * 32);
+    ACL_GEMM16_MAINLOOP(T, KS, TM, TN, kbeg, nk, As, Bs, BM * LDQ, BN * LDQ, wm * TM * 32, wn * TN * 32);
 
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -358,7 +365,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
     }
 }
 
-template <class T, int WM, int WN, int TM, int TN>
+template <class T, int KS, int WM, int WN, int TM, int TN>
 int launch_dgrad16(const ConvGeom& g, DgFP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     int mmax = 0;
@@ -375,28 +382,38 @@ int launch_dgrad16(const ConvGeom& g, DgFP p, hipStream_t st) {
     p.Mc = mmax;
     p.tiles_n = cdiv(g.Ci, BN);
     p.nwg = cdiv(p.Mc, BM) * p.tiles_n;
-    const int nk_min = ((g.k + g.s - 1) / g.s) * ((g.k + g.s - 1) / g.s) * (g.Co / BK16);
+    const int nk_min = ((g.k + g.s - 1) / g.s) * ((g.k + g.s - 1) / g.s) * (g.Co / (16 * KS));   // k-tiles of the largest parity class
     const int nblk = p.nwg * g.s * g.s;
     p.ksplit = 1;
-    if (nblk < 128 && nk_min >= 16) p.ksplit = max(1, min(nk_min / 4, 512 / nblk));
+    if (nblk < 128 && nk_min * KS >= 32) p.ksplit = max(1, min(nk_min * KS / 8, 512 / nblk));
     if (p.ksplit > 1 && p.mode == 1 && !p.accumulate) {
         hipError_t e = hipMemsetAsync(p.dxp, 0, (size_t)g.B * g.Hi * g.Wi * g.Ci * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "memset dx");
     }
-    hipLaunchKernelGGL((conv_dgrad16_kernel<T, WM, WN, TM, TN>), dim3(p.nwg, 1, g.s * g.s * p.ksplit), dim3(WM * WN * 64), 0, st, p);
+    hipLaunchKernelGGL((conv_dgrad16_kernel<T, KS, WM, WN, TM, TN>), dim3(p.nwg, 1, g.s * g.s * p.ksplit), dim3(WM * WN * 64), 0, st, p);
     ACL_CHECK_LAUNCH("conv_dgrad16_kernel");
     return ACLGAN_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // wgrad (Cout % 64 == 0, Cin % BN == 0 "single tap"): M = Cout, N = (tap, cin), K = pixels (split across blockIdx.z)
+// A slice walks its pixel range in sub-chunks of <= 1024 pixels (the per-pixel gather table lives in LDS).  No atomics:
+// with one slice the tile is added straight into dw; with several, every slice stores its tile (and its bias column
+// sums) to scratch and wgrad16_finish_kernel adds the slices in ORDER -- the weight gradient is reproducible bit for bit.
 // ------------------------------------------------------------------------------------------
+struct Wg16X {          // extras of the 16-bit kernel on top of WgFP
+    float* part;        // [slice][phase][tile][BM][BN] partial tiles in MFMA-fragment row/column order (nullptr: single slice)
+    float* part_b;      // [slice][phase][Co] partial bias sums
+    int ny;
+};
+
 template <class T, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p) {
+__global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, Wg16X xp) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     static_assert(BM % 64 == 0 && BN % 64 == 0 && BM + BN <= NT, "one staging unit (4 channels x 8 pixels) per thread, wave-uniform roles");
+    constexpr int CH = 1024;                   // pixels per sub-chunk
     __shared__ u32x4 smem[2 * (BM + BN) * LDQ];
-    __shared__ int2 pinfo[WG16_MAX_CHUNK];     // per chunk pixel: .x = source pixel of this workgroup's tap, .y = dy pixel
+    __shared__ int2 pinfo[CH + BK16];          // per sub-chunk pixel: .x = source pixel of this workgroup's tap, .y = dy pixel
     u32x4* As = smem;
     u32x4* Bs = smem + 2 * BM * LDQ;
 
@@ -406,20 +423,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p) {
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int pbeg = blockIdx.z * p.chunk;
     const int pend = min(p.P, pbeg + p.chunk);
-    if (pbeg >= pend) return;
     const int phase = p.phases ? (int)blockIdx.y : 0;
     float* dwbase = p.dw + (size_t)phase * p.Co * p.Kn;
     const int py = phase >> 1, px = phase & 1;
-
     const int st_tap = n0 / p.Ci, st_ky = st_tap / p.k, st_kx = st_tap - st_ky * p.k;   // the whole N tile lies inside ONE filter tap
-    for (int i = tid; i < pend - pbeg + BK16; i += NT) {     // + BK16: the clamped tail tile reads past the end
-        int b, oy, ox;
-        wg_coord(p, min(pbeg + i, pend - 1), b, oy, ox);
-        const int dyp = p.phases ? (b * p.Hf + 2 * (oy + 1) + py) * p.Wf + 2 * (ox + 1) + px : (b * p.Ho + oy) * p.Wo + ox;
-        const int iy = refl(oy * p.s - p.p + st_ky, p.Hu) >> p.up, ix = refl(ox * p.s - p.p + st_kx, p.Wu) >> p.up;
-        pinfo[i] = make_int2(b * p.Hi * p.Wi + iy * p.Wi + ix, dyp);
-    }
-    __syncthreads();
 
     // staging roles (wave-uniform): threads [0, BM) build the A tile (dy: rows = cout), [BM, BM+BN) the B tile (x: rows =
     // cin of the tap); a unit = 4 consecutive channels x 8 consecutive chunk pixels
@@ -429,43 +436,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p) {
     const int cg = u % ncg, pg = u / ncg;           // pg in 0..3: pixels 8pg .. 8pg+7 of the k-tile
     const float* src = isA ? p.dy : p.x;
     const int cstride = isA ? p.Co : p.Ci;
-    int chan = isA ? m0 + 4 * cg : (n0 - st_tap * p.Ci) + 4 * cg;
-    if (chan >= cstride) chan = 0;                  // ragged M tile: rows never stored
+    const int chan = isA ? m0 + 4 * cg : (n0 - st_tap * p.Ci) + 4 * cg;
     u32x4* mytile = isA ? As : Bs;
     const int tstride = (isA ? BM : BN) * LDQ;
     f32x4 rr[8];
     float zm[8];
     const bool do_bias = p.db != nullptr && (tile % p.tiles_n) == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-
-    auto fetch = [&](int kt) __attribute__((always_inline)) {
-        const int pb = kt * BK16 + 8 * pg;    // chunk-relative
-        if (isA || isB) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int2 pi = pinfo[pb + j];
-                rr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
-                zm[j] = pbeg + pb + j < pend ? 1.f : 0.f;     // pixels past the chunk contribute nothing (masking one operand is enough)
-            }
-        }
-    };
-    auto stage = [&](int buf, bool real) __attribute__((always_inline)) {
-        if (isA || isB) {
-            u32x4* t = mytile + buf * tstride;
-            f32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = rr[j] * zm[j];
-            if (isA && real) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += v[j];
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x8 k8 = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
-                t[(c * ncg + cg) * LDQ + pg] = T::pack(k8);     // row interleave: channel 4cg+c -> row c*ncg + cg
-            }
-        }
-    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -475,48 +452,161 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    ACL_GEMM16_MAINLOOP(T, TM, TN, 0, (pend - pbeg + BK16 - 1) / BK16, As, Bs, BM * LDQ, BN * LDQ, wm * TM * 32, wn * TN * 32);
+    for (int cb = pbeg; cb < pend; cb += CH) {
+        const int ce = min(pend, cb + CH);
+        for (int i = tid; i < ce - cb + BK16; i += NT) {     // + BK16: the clamped tail tile reads past the end
+            int b, oy, ox;
+            wg_coord(p, min(cb + i, ce - 1), b, oy, ox);
+            const int dyp = p.phases ? (b * p.Hf + 2 * (oy + 1) + py) * p.Wf + 2 * (ox + 1) + px : (b * p.Ho + oy) * p.Wo + ox;
+            const int iy = refl(oy * p.s - p.p + st_ky, p.Hu) >> p.up, ix = refl(ox * p.s - p.p + st_kx, p.Wu) >> p.up;
+            pinfo[i] = make_int2(b * p.Hi * p.Wi + iy * p.Wi + ix, dyp);
+        }
+        __syncthreads();
 
-    if (do_bias) {   // block-uniform; the main loop ended with a barrier, LDS is free
+        auto fetch = [&](int kt) __attribute__((always_inline)) {
+            const int pb = kt * BK16 + 8 * pg;    // sub-chunk relative
+            if (isA || isB) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int2 pi = pinfo[pb + j];
+                    rr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
+                    zm[j] = cb + pb + j < ce ? 1.f : 0.f;     // pixels past the sub-chunk contribute nothing (masking both operands is harmless)
+                }
+            }
+        };
+        auto stage = [&](int buf, bool real) __attribute__((always_inline)) {
+            if (isA || isB) {
+                u32x4* t = mytile + buf * tstride;
+                f32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = rr[j] * zm[j];
+                if (isA && real) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += v[j];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x8 k8 = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
+                    t[(c * ncg + cg) * LDQ + pg] = T::pack(k8);     // row interleave: channel 4cg+c -> row c*ncg + cg
+                }
+            }
+        };
+        ACL_GEMM16_MAINLOOP(T, 2, TM, TN, 0, (ce - cb + BK16 - 1) / BK16, As, Bs, BM * LDQ, BN * LDQ, wm * TM * 32, wn * TN * 32);
+        // (the main loop ends with a barrier: pinfo and both LDS buffers are free for the next sub-chunk)
+    }
+
+    const bool partial = xp.part != nullptr;
+    if (do_bias) {   // block-uniform
         float* red = reinterpret_cast<float*>(smem);   // [4 pixel groups][BM]
         if (isA) *reinterpret_cast<f32x4*>(red + pg * BM + 4 * cg) = bsum;
         __syncthreads();
-        if (tid < BM && m0 + tid < p.Co) atomicAdd(p.db + m0 + tid, red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid]);
+        if (tid < BM) {
+            const float t = red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid];
+            if (partial) xp.part_b[((size_t)blockIdx.z * xp.ny + phase) * p.Co + m0 + tid] = t;
+            else p.db[m0 + tid] += t;          // single slice: this workgroup is the only writer of these channels
+        }
     }
     const int l31 = lane & 31, lh = lane >> 5;
     constexpr int MQ = BM / 4, NQ = BN / 4;
+    if (partial) {
+        float* pt = xp.part + (((size_t)blockIdx.z * xp.ny + phase) * p.nwg + tile) * (BM * BN);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rw = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pt[rw * BN + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];      // fragment order: 128-byte coalesced rows
+                }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int cr = wn * TN * 32 + j * 32 + l31;              // LDS row of the B tile -> channel 4*(row % NQ) + row / NQ
         const int n = n0 + 4 * (cr % NQ) + cr / NQ;
-        if (n >= p.Kn) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rw = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int m = m0 + 4 * (rw % MQ) + rw / MQ;
-                if (m < p.Co) atomicAdd(dwbase + (size_t)m * p.Kn + n, acc[i][j][r]);
+                dwbase[(size_t)m * p.Kn + n] += acc[i][j][r];
             }
         }
     }
 }
 
+// dw[phase][m][n..n+3] += sum over slices (in order) of the partial tiles; db[m] += sum over slices and phases
+__global__ void wgrad16_finish_kernel(WgFP p, Wg16X xp, int BM, int BN, int splits) {
+    const int MQ = BM / 4, NQ = BN / 4, N4 = p.Kn >> 2;
+    const int64_t n = (int64_t)xp.ny * p.Co * N4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int n4 = (int)(i % N4);
+        int64_t t = i / N4;
+        const int m = (int)(t % p.Co), phase = (int)(t / p.Co);
+        const int tm = m / BM, ml = m - tm * BM, tn = (n4 * 4) / BN, nl = n4 * 4 - tn * BN;
+        const int rw = (ml & 3) * MQ + (ml >> 2), q = nl >> 2;
+        const int tile = tm * p.tiles_n + tn;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splits; ++z) {
+            const float* pt = xp.part + (((size_t)z * xp.ny + phase) * p.nwg + tile) * ((size_t)BM * BN) + (size_t)rw * BN + q;
+            s[0] += pt[0]; s[1] += pt[NQ]; s[2] += pt[2 * NQ]; s[3] += pt[3 * NQ];
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(p.dw + ((size_t)phase * p.Co + m) * p.Kn + n4 * 4);
+        *o += s;
+    }
+    if (p.db)
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.Co; m += gridDim.x * 256) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z)
+                for (int ph = 0; ph < xp.ny; ++ph) s += xp.part_b[((size_t)z * xp.ny + ph) * p.Co + m];
+            p.db[m] += s;
+        }
+}
+
+// tile shape and split plan of a wgrad launch (shared by the launcher and the scratch-size query)
+struct Wg16Plan { int BM, BN, tiles_n, nwg, splits, chunk; };
+Wg16Plan wgrad16_plan(int Co, int Ci, int Kn, int P, int ny) {
+    Wg16Plan q;
+    q.BM = Co % 128 == 0 ? 128 : 64;
+    q.BN = Ci % 128 == 0 ? 128 : 64;
+    q.tiles_n = Kn / q.BN;
+    q.nwg = (Co / q.BM) * q.tiles_n;
+    const int target = 512;                                  // one resident round at 2 workgroups per CU
+    int splits = std::max(1, target / (q.nwg * ny));
+    splits = std::max(1, std::min(splits, cdiv(P, 512)));    // a slice is at least 16 k-tiles deep
+    q.chunk = cdiv(cdiv(P, splits), BK16) * BK16;
+    q.splits = cdiv(P, q.chunk);
+    return q;
+}
+size_t wgrad16_partial_bytes(const Wg16Plan& q, int Co, int ny) {
+    if (q.splits <= 1 && ny == 1) return 0;      // (phase launches always go through the partials: 4 phases share one db)
+    return ((size_t)q.splits * ny * q.nwg * q.BM * q.BN + (size_t)q.splits * ny * Co) * sizeof(float);
+}
+
 template <class T, int WM, int WN, int TM, int TN>
-int launch_wgrad16(const ConvGeom& g, WgFP p, hipStream_t st) {
+int launch_wgrad16(const ConvGeom& g, WgFP p, void* part, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    if (p.Ci % BN != 0) { set_error("wgrad16: Cin %d is not a multiple of the N tile %d", p.Ci, BN); return ACLGAN_EINVAL; }
-    p.tiles_n = cdiv(p.Kn, BN);
-    p.nwg = cdiv(g.Co, BM) * p.tiles_n;
-    const int target = 1536;
     const int ny = p.phases ? 4 : 1;
-    int splits = max(1, target / (p.nwg * ny));
-    splits = max(1, min(splits, cdiv(p.P, 256)));
-    splits = max(splits, cdiv(p.P, 1024));                // the per-chunk pixel table lives in LDS
-    p.chunk = cdiv(cdiv(p.P, splits), BK16) * BK16;
-    splits = cdiv(p.P, p.chunk);
-    hipLaunchKernelGGL((conv_wgrad16_kernel<T, WM, WN, TM, TN>), dim3(p.nwg, ny, splits), dim3(WM * WN * 64), 0, st, p);
+    const Wg16Plan q = wgrad16_plan(g.Co, p.Ci, p.Kn, p.P, ny);
+    if (q.BM != BM || q.BN != BN) { set_error("wgrad16: tile plan mismatch"); return ACLGAN_EINVAL; }
+    p.tiles_n = q.tiles_n; p.nwg = q.nwg; p.chunk = q.chunk;
+    Wg16X xp;
+    xp.ny = ny; xp.part = nullptr; xp.part_b = nullptr;
+    const bool use_part = q.splits > 1 || ny > 1;
+    if (use_part) {
+        if (!part) { set_error("wgrad16: %d slices need the scratch buffer (aclgan_conv2d_wgrad16_scratch_bytes)", q.splits); return ACLGAN_EINVAL; }
+        xp.part = (float*)part;
+        xp.part_b = xp.part + (size_t)q.splits * ny * q.nwg * BM * BN;
+    }
+    hipLaunchKernelGGL((conv_wgrad16_kernel<T, WM, WN, TM, TN>), dim3(p.nwg, ny, q.splits), dim3(WM * WN * 64), 0, st, p, xp);
     ACL_CHECK_LAUNCH("conv_wgrad16_kernel");
+    if (use_part) {
+        const int64_t n = (int64_t)ny * g.Co * (p.Kn / 4);
+        hipLaunchKernelGGL(wgrad16_finish_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, p, xp, BM, BN, q.splits);
+        ACL_CHECK_LAUNCH("wgrad16_finish_kernel");
+    }
     return ACLGAN_OK;
 }
 
@@ -595,6 +685,13 @@ __global__ void up5_merge16_kernel(const float* __restrict__ w, u16* __restrict_
     }
 }
 
+// ACLGAN_TILE16=wide: 128 x 256 tiles (8 waves) for the 256-channel layers (A/B switch; default off, see launch_fwd16_ks)
+bool wide_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_TILE16"); v = (e && e[0] == 'w') ? 1 : 0; }
+    return v == 1;
+}
+
 // ---- eligibility ----
 bool fwd16_ok(const ConvGeom& g) { return fast_enabled() && g.Ci % 32 == 0 && g.Co % 32 == 0 && (g.up == 0 || up5_eligible(g)); }
 bool dgrad16_ok(const ConvGeom& g) { return fast_enabled() && g.Ci % 32 == 0 && g.Co % 32 == 0 && (g.up == 0 || up5_eligible(g)); }
@@ -612,24 +709,38 @@ FwdFP fwd_params(const ConvGeom& g, const float* x, const u16* w16, const float*
     return p;
 }
 
+// k-steps per tile: 64-deep tiles whenever the GEMM k axis (Cin: forward, Cout: dgrad) is a multiple of 64
+// (not for the 256 x 64 tile of the 64-channel layers: 64-deep it needs 93 KB of LDS and > 256 registers -> one workgroup per CU)
+inline int fwd16_bk(const ConvGeom& g) { return (g.Ci % 64 == 0 && g.Co > 64) ? 64 : 32; }
+template <class T, int KS>
+int launch_fwd16_ks(const ConvGeom& g, const FwdFP& p, hipStream_t st) {
+    // (a 128 x 256 tile with 8 waves -- every activation row fetched once per tap -- was measured: the isolated ResBlock
+    //  kernel gains 9 %, the whole step loses 2 %: ACLGAN_TILE16=wide keeps it selectable)
+    if (g.Co % 256 == 0 && wide_tiles()) return launch_fwd16<T, KS, 2, 4, 2, 2>(g, p, st);
+    if (g.Co > 64) return launch_fwd16<T, KS, 2, 2, 2, 2>(g, p, st);
+    return launch_fwd16<T, KS, 4, 1, 2, 2>(g, p, st);      // Co 32 / 64: 256 x 64
+}
 template <class T>
 int launch_fwd16_any(const ConvGeom& g, const FwdFP& p, hipStream_t st) {
-    if (g.Co > 64) return launch_fwd16<T, 2, 2, 2, 2>(g, p, st);
-    return launch_fwd16<T, 4, 1, 2, 2>(g, p, st);      // Co 32 / 64: 256 x 64
+    return fwd16_bk(g) == 64 ? launch_fwd16_ks<T, 4>(g, p, st) : launch_fwd16_ks<T, 2>(g, p, st);
+}
+template <class T, int KS>
+int launch_dgrad16_ks(const ConvGeom& g, const DgFP& p, hipStream_t st) {
+    if (g.Ci % 256 == 0 && wide_tiles()) return launch_dgrad16<T, KS, 2, 4, 2, 2>(g, p, st);
+    if (g.Ci > 64) return launch_dgrad16<T, KS, 2, 2, 2, 2>(g, p, st);
+    return launch_dgrad16<T, KS, 4, 1, 2, 2>(g, p, st);
 }
 template <class T>
 int launch_dgrad16_any(const ConvGeom& g, const DgFP& p, hipStream_t st) {
-    if (g.Ci > 64) return launch_dgrad16<T, 2, 2, 2, 2>(g, p, st);
-    return launch_dgrad16<T, 4, 1, 2, 2>(g, p, st);
+    return (p.Co % 64 == 0 && g.Ci > 64) ? launch_dgrad16_ks<T, 4>(g, p, st) : launch_dgrad16_ks<T, 2>(g, p, st);
 }
 template <class T>
-int launch_wgrad16_any(const ConvGeom& g, const WgFP& p, hipStream_t st) {
-    if (g.Co % 128 == 0 && p.Ci % 128 == 0) return launch_wgrad16<T, 2, 2, 2, 2>(g, p, st);   // 128 x 128
-    if (g.Co % 128 == 0) return launch_wgrad16<T, 2, 2, 2, 1>(g, p, st);                       // 128 x 64 (Cin = 64)
-    if (p.Ci % 128 == 0) return launch_wgrad16<T, 2, 2, 1, 2>(g, p, st);                       // 64 x 128 (Cout = 64)
-    return launch_wgrad16<T, 2, 2, 1, 1>(g, p, st);                                            // 64 x 64: half the threads stage
+int launch_wgrad16_any(const ConvGeom& g, const WgFP& p, void* part, hipStream_t st) {
+    if (g.Co % 128 == 0 && p.Ci % 128 == 0) return launch_wgrad16<T, 2, 2, 2, 2>(g, p, part, st);   // 128 x 128
+    if (g.Co % 128 == 0) return launch_wgrad16<T, 2, 2, 2, 1>(g, p, part, st);                       // 128 x 64 (Cin = 64)
+    if (p.Ci % 128 == 0) return launch_wgrad16<T, 2, 2, 1, 2>(g, p, part, st);                       // 64 x 128 (Cout = 64)
+    return launch_wgrad16<T, 2, 2, 1, 1>(g, p, part, st);                                            // 64 x 64: half the threads stage
 }
-
 template <class T>
 int fwd16_t(const ConvGeom& g, const float* x, const float* w, const u16* w16, const float* bias, float* y, void* scratch, hipStream_t st) {
     if (up5_eligible(g)) {
@@ -712,27 +823,41 @@ WgFP wg_params(const ConvGeom& g, const float* x, const float* dy, float* dw, fl
     return p;
 }
 
+// up5 scratch: [dwp: 4 x Cout x 9 x Cin fp32][partial tiles of the phase launch, reused by the ring launch]
+size_t up5_dwp_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * sizeof(float) + 255) & ~(size_t)255; }
+int up5_ring_pixels(const ConvGeom& g) { return g.B * (g.Ho * g.Wo - (g.Ho - 4) * (g.Wo - 4)); }
+
+size_t wgrad16_scratch(const ConvGeom& g) {
+    if (up5_eligible(g)) {
+        const Wg16Plan a = wgrad16_plan(g.Co, g.Ci, 9 * g.Ci, g.B * (g.Hi - 2) * (g.Wi - 2), 4);
+        const Wg16Plan b = wgrad16_plan(g.Co, g.Ci, g.K, up5_ring_pixels(g), 1);
+        return up5_dwp_bytes(g) + std::max(wgrad16_partial_bytes(a, g.Co, 4), wgrad16_partial_bytes(b, g.Co, 1));
+    }
+    return wgrad16_partial_bytes(wgrad16_plan(g.Co, g.Ci, g.K, g.M, 1), g.Co, 1);
+}
+
 template <class T>
 int wgrad16_t(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
+    if (wgrad16_scratch(g) && !scratch) { set_error("conv_wgrad16: this layer needs its scratch buffer"); return ACLGAN_EINVAL; }
     if (up5_eligible(g)) {
-        if (!scratch) { set_error("conv_wgrad16: the upsample+5x5 layer needs its scratch buffer"); return ACLGAN_EINVAL; }
         float* dwp = (float*)scratch;
+        void* part = (char*)scratch + up5_dwp_bytes(g);
         hipError_t e = hipMemsetAsync(dwp, 0, (size_t)4 * g.Co * 9 * g.Ci * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "memset dwp");
         WgFP p = wg_params(g, x, dy, dwp, db);
         p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.k = 3; p.s = 1; p.p = 0; p.up = 0; p.Hu = g.Hi; p.Wu = g.Wi;
         p.P = g.B * p.Ho * p.Wo; p.Kn = 9 * g.Ci; p.phases = 1; p.Hf = g.Ho; p.Wf = g.Wo;
-        int rc = launch_wgrad16_any<T>(g, p, st);
+        int rc = launch_wgrad16_any<T>(g, p, part, st);
         if (rc) return rc;
         const int64_t ns = (int64_t)g.Co * 25 * (g.Ci / 4);
         hipLaunchKernelGGL(up5_scatter_kernel, dim3((int)std::min<int64_t>(cdiv64(ns, 256), 2048)), dim3(256), 0, st, dwp, dw, g.Co, g.Ci);
         ACL_CHECK_LAUNCH("up5_scatter_kernel");
         p = wg_params(g, x, dy, dw, db);
         p.ring = 2;
-        p.P = g.B * (g.Ho * g.Wo - (g.Ho - 4) * (g.Wo - 4));
-        return launch_wgrad16_any<T>(g, p, st);
+        p.P = up5_ring_pixels(g);
+        return launch_wgrad16_any<T>(g, p, part, st);
     }
-    return launch_wgrad16_any<T>(g, wg_params(g, x, dy, dw, db), st);
+    return launch_wgrad16_any<T>(g, wg_params(g, x, dy, dw, db), scratch, st);
 }
 
 }  // namespace
@@ -746,11 +871,11 @@ bool conv16_eligible(const ConvGeom& g, int which) {
 
 size_t conv_fwd16_scratch_bytes(const ConvGeom& g) {
     if (!fwd16_ok(g)) return 0;
-    if (up5_eligible(g)) return up5_w16_bytes(g) + fwd_partial_bytes(g, 2, BK16);
-    return fwd_partial_bytes(g, 0, BK16);
+    if (up5_eligible(g)) return up5_w16_bytes(g) + fwd_partial_bytes(g, 2, fwd16_bk(g));
+    return fwd_partial_bytes(g, 0, fwd16_bk(g));
 }
 size_t conv_dgrad16_scratch_bytes(const ConvGeom& g) { return dgrad16_ok(g) && up5_eligible(g) ? up5_w16_bytes(g) : 0; }
-size_t conv_wgrad16_scratch_bytes(const ConvGeom& g) { return wgrad16_ok(g) && up5_eligible(g) ? (size_t)4 * g.Co * 9 * g.Ci * sizeof(float) : 0; }
+size_t conv_wgrad16_scratch_bytes(const ConvGeom& g) { return wgrad16_ok(g) ? wgrad16_scratch(g) : 0; }
 
 int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st) {
     if (!fwd16_ok(g)) return ACLGAN_EUNSUPPORTED;

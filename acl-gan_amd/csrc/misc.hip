@@ -369,6 +369,26 @@ int focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const flo
     return ACLGAN_OK;
 }
 
+__global__ void focus_translation_nchw_kernel(const float* __restrict__ fg, int64_t fgs, const float* __restrict__ bg, int64_t bgs,
+                                              const float* __restrict__ fo, int64_t fos, float* __restrict__ out, int HW, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const int64_t t = i / HW;
+        const int c = (int)(t % 3);
+        const int64_t b = t / 3;
+        const float m = (fo[b * fos + p] + 1.f) * 0.5f;
+        out[i] = fg[b * fgs + (int64_t)c * HW + p] * m + bg[b * bgs + (int64_t)c * HW + p] * (1.f - m);
+    }
+}
+int focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg, int64_t bg_bstride, const float* focus, int64_t focus_bstride,
+                           float* out, int B, int HW, hipStream_t st) {
+    const int64_t n = (int64_t)B * 3 * HW;
+    hipLaunchKernelGGL(focus_translation_nchw_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, fg, fg_bstride, bg, bg_bstride,
+                       focus, focus_bstride, out, HW, n);
+    ACL_CHECK_LAUNCH("focus_translation_nchw_kernel");
+    return ACLGAN_OK;
+}
+
 // ---- LSGAN: loss_slot += weight*mean((o-t)^2); d_o = gscale*weight*2(o-t)/n ----
 __global__ void __launch_bounds__(256) lsgan_kernel(const float* __restrict__ o, int n, float target, float weight, float* loss_slot,
                                                     float* __restrict__ d_o, float gscale, const float* __restrict__ lscale) {

@@ -441,9 +441,23 @@ class aclgan_Trainer:
     def update_learning_rate(self):   # trainer.py:295-299, called every iteration (train.py:101)
         self._sched_calls += 1
 
-    def focus_translation(self, x_fg, x_bg, x_focus):   # trainer.py:85-88 (sample()/test.py only; tiny, elementwise)
-        m = ((x_focus + 1) / 2).repeat(1, 3, 1, 1)
-        return x_fg * m + x_bg * (1 - m)
+    def focus_translation(self, x_fg, x_bg, x_focus):
+        """trainer.py:85-88 for sample() / test.py, on NCHW tensors, through the library's blend kernel.  x_fg / x_focus may
+        be channel slices of one decoder output (only the batch stride has to be regular)."""
+        B, Cc, H, W = x_fg.shape
+        if Cc != 3 or x_focus.shape[1] != 1 or tuple(x_bg.shape) != (B, 3, H, W):
+            raise L.AclganError("focus_translation: expected (B,3,H,W), (B,3,H,W), (B,1,H,W)")
+
+        def dense(t):   # each sample's C*H*W block contiguous; any batch stride
+            t = t.to(self.device, torch.float32)
+            ok = t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W
+            return t if ok else t.contiguous()
+        fg, bg, fo = dense(x_fg), dense(x_bg), dense(x_focus)
+        out = torch.empty(B, 3, H, W, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib.aclgan_focus_translation_nchw(L.ptr(fg), fg.stride(0), L.ptr(bg), bg.stride(0), L.ptr(fo), fo.stride(0),
+                                                        L.ptr(out), B, H * W, self._st()), "focus_translation")
+        return out
 
     def sample(self, x_a, x_b):
         """trainer.py:179-245, focus branch: per-image eval forward; returns the same 9-tuple."""

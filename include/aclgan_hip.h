@@ -264,6 +264,41 @@ int aclgan_avgpool3s2_fwd(int B, int H, int W, int C, const float* x, float* y, 
 int aclgan_avgpool3s2_bwd(int B, int H, int W, int C, const float* dy, float* dx, int accumulate,
                           void* stream);
 
+/* LinearBlock / MLP layer (networks.py:373-418, 280-292) and the style head's 1x1 conv on a pooled vector (networks.py:223):
+ * y[b][o] = act(sum_i x[b][i] W[o][i] + bias[o]).  bwd: dy is modified in place by the activation backward; dx is
+ * overwritten (may be NULL); dw, db accumulate (may be NULL). */
+int aclgan_linear_fwd(int B, int I, int O, const float* x, const float* w, const float* bias, int act, float* y, void* stream);
+int aclgan_linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, const float* w, int act,
+                      float* dx, float* dw, float* db, void* stream);
+/* AdaptiveAvgPool2d(1) (networks.py:222), NHWC [B][HW][C] -> [B][C] */
+int aclgan_gap_fwd(int B, int HW, int C, const float* x, float* y, void* stream);
+int aclgan_gap_bwd(int B, int HW, int C, const float* dy, float* dx, int accumulate, void* stream);
+/* aclgan_Trainer.focus_translation (trainer.py:85-88) fused with the 6-channel pair concat (trainer.py:132-133), NHWC:
+ * dec4 [B][HW][4] (decoder output: ch0-2 image, ch3 focus), bg [B][HW][3] -> out [B][HW][3]; optional pair [B][HW][6] =
+ * (pair_first, out).  bwd: d_dec4 += (zero-initialise it), d_bg (+)= (may be NULL); d_out / d_pair may each be NULL. */
+int aclgan_focus_blend_fwd(int B, int HW, const float* dec4, const float* bg, float* out, const float* pair_first,
+                           float* pair, void* stream);
+int aclgan_focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const float* d_out, const float* d_pair,
+                           float* d_dec4, float* d_bg, int bg_accumulate, void* stream);
+/* the same blend on the reference's NCHW tensors, for sample() / test.py (trainer.py:179-245, test.py:73-76): fg, bg
+ * (B,3,H,W), focus (B,1,H,W), out (B,3,H,W) contiguous; *_bstride = floats between consecutive samples of that input
+ * (so fg / focus may be the two channel slices of one (B,4,H,W) decoder output) */
+int aclgan_focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg, int64_t bg_bstride,
+                                  const float* focus, int64_t focus_bstride, float* out, int B, int HW, void* stream);
+/* MsImageDis.calc_*_loss, one scale (networks.py:67,83,98): *loss_slot += weight*mean((o-target)^2);
+ * d_o (may be NULL) = gscale*weight*2(o-target)/n */
+int aclgan_lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, void* stream);
+/* recon_criterion (trainer.py:61-62): *loss_slot += mean|a[..., :3] - b| over npix pixels; a has a_channels (3 or 4) NHWC
+ * channels, b has 3; d_a (may be NULL) (+)= gscale*sign/(3*npix) on channels 0-2 */
+int aclgan_l1_loss(const float* a, int a_channels, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale,
+                   int d_accumulate, void* stream);
+/* focus losses of one mask (trainer.py:146-158): dec4 NHWC [npix][4], m = (ch3+1)/2;
+ * *size_slot = delta*(relu(sum(m-upper))^2 + relu(sum(lower-m))^2), *digit_slot = sum 1/(|m-0.5|+eps);
+ * d_dec4 (may be NULL) ch3 += scale * d(size+digit)/d ch3.  scratch: aclgan_focus_loss_scratch_bytes(npix). */
+size_t aclgan_focus_loss_scratch_bytes(int64_t npix);
+int aclgan_focus_loss(const float* dec4, int64_t npix, float delta, float upper, float lower, float eps, float scale,
+                      float* size_slot, float* digit_slot, float* d_dec4, void* scratch, void* stream);
+
 /* torch.optim.Adam over a flat buffer (trainer.py:39-42,170,293) */
 int aclgan_adam_flat(float* p, const float* g, float* m, float* v, int64_t n,
                      const aclgan_adam* opt, int step, void* stream);

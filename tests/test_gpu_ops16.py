@@ -169,6 +169,10 @@ def test_conv_wgrad16(L, case, dt):
     assert rel_err(dw, ohwi(wr.grad)) < EXACT_TOL      # exact path too for the sub-pixel layers: wgrad merges nothing before rounding
     assert rel_err(dw, ohwi(wf.grad)) < PREC_TOL[dt]
     assert rel_err(db, bf.grad) < EXACT_TOL            # the bias gradient is summed from the UNROUNDED fp32 dy
+    # no atomics anywhere in the 16-bit weight gradient: slices are reduced in order -> reproducible bit for bit
+    dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
+    L.check(L.lib.aclgan_conv2d_wgrad16(C.byref(d), L.DTYPE[dt], L.ptr(xg), L.ptr(dyg), L.ptr(dw2), L.ptr(db2), L.ptr(scr), L.stream_ptr()))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
 def test_ineligible_shapes_are_refused(L):
