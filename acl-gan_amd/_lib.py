@@ -63,6 +63,8 @@ LOSS_NAMES = [
 vp, ci, cf, i64, sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 # aclgan_bucket_fn: void (*)(void* user, int group, int bucket, int64_t offset, int64_t numel)
 BUCKET_FN = C.CFUNCTYPE(None, vp, ci, ci, i64, i64)
+# aclgan_sync_fn: void (*)(void* user, float* sums_dev, int n)
+SYNC_FN = C.CFUNCTYPE(None, vp, vp, ci)
 
 # every symbol include/aclgan_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -80,6 +82,8 @@ SIGNATURES = {
     "aclgan_gen_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
     "aclgan_dis_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
     "aclgan_set_grad_buckets": (ci, [vp, i64, BUCKET_FN, vp]),
+    "aclgan_set_forward_sync": (ci, [vp, SYNC_FN, vp, ci]),
+    "aclgan_focus_loss_global": (ci, [vp, i64, vp, i64, cf, cf, cf, cf, cf, vp, vp, vp, vp]),
     "aclgan_bucket_schedule": (ci, [vp, ci, ci, ci, ci, ci, C.POINTER(ci), ci, C.POINTER(ci)]),
     "aclgan_zero_grad": (ci, [vp, ci, vp]),
     "aclgan_adam_step": (ci, [vp, ci, C.POINTER(Adam), ci, vp]),

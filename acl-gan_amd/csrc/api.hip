@@ -188,6 +188,13 @@ int aclgan_focus_loss(const float* dec4, int64_t npix, float delta, float upper,
     return focus_loss_finish(dec4, npix, (const float*)scratch, delta, upper, lower, eps, scale, size_slot, digit_slot, d_dec4, (hipStream_t)stream);
 }
 
+int aclgan_focus_loss_global(const float* dec4, int64_t npix, const float* totals, int64_t npix_total, float delta, float upper, float lower,
+                             float eps, float scale, float* size_slot, float* digit_slot, float* d_dec4, void* stream) {
+    ACL_REQUIRE(dec4 && npix > 0 && totals && npix_total >= npix && size_slot && digit_slot, "focus_loss_global: bad arguments");
+    return focus_loss_finish(dec4, npix, nullptr, delta, upper, lower, eps, scale, size_slot, digit_slot, d_dec4, (hipStream_t)stream, nullptr, totals,
+                             npix_total);
+}
+
 size_t aclgan_norm_scratch_bytes(int B, int HW, int C) { return norm_scratch_bytes(B, HW, C); }
 int aclgan_norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const float* w, const float* b, int w_stride,
                     const float* residual, float* y, float* mean, float* rstd, void* scratch, void* stream) {

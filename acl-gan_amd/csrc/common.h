@@ -55,7 +55,8 @@ int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float
 size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g);
 int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* dxp, float* dx, int accumulate, bool* direct, hipStream_t st);
 // also accumulates the bias gradient into db when db != nullptr
-int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st);
+int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr);
+size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g);
 
 // 16-bit MFMA kernels (conv_fast16.hip): operands rounded to bf16 / fp16, fp32 accumulation and outputs.
 // which: 0 forward, 1 dgrad, 2 wgrad.  EUNSUPPORTED when the shape is not eligible.
@@ -123,8 +124,13 @@ int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* l
 int focus_sums_blocks(int64_t npix);
 int focus_sums(const float* dec4, int64_t npix, float eps, float upper, float* part, hipStream_t st);
 // adds the partials in order, writes size/digit into the loss slots and adds the focus gradient into d_dec4 channel 3
+// totals (optional, device float[2]): sum(m - upper) and the digit sum over a larger pixel set (the GLOBAL batch of a
+// data-parallel job, npix_total pixels) to be used instead of this call's own partials
 int focus_loss_finish(const float* dec4, int64_t npix, const float* part, float delta, float upper, float lower, float eps,
-                      float scale, float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st, const float* lscale = nullptr);
+                      float scale, float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st, const float* lscale = nullptr,
+                      const float* totals = nullptr, int64_t npix_total = 0);
+// totals[2*i], totals[2*i+1] = ordered sums of mask i's partials (mask i's partials start at part + i*2*focus_sums_blocks(npix))
+int focus_totals(const float* part, int64_t npix, int nmask, float* totals, hipStream_t st);
 // Adam under fp16 dynamic loss scaling: overflow scan, update with g/S (or skip), scale update -- all on the device
 int adam_flat_scaled(float* p, const float* g, float* m, float* v, int64_t n, const aclgan_adam* o, int step, float* state, int group, hipStream_t st);
 

@@ -720,7 +720,7 @@ static int launch_wgrad(const ConvGeom& g, WgP p, hipStream_t st) {
     return ACLGAN_OK;
 }
 
-size_t conv_wgrad_scratch_bytes(const ConvGeom& g) { return std::max(conv_up5_scratch_bytes(g), conv_wgrad_small_scratch_bytes(g)); }
+size_t conv_wgrad_scratch_bytes(const ConvGeom& g) { return std::max(conv_wgrad_fast_scratch_bytes(g), conv_wgrad_small_scratch_bytes(g)); }
 
 int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
     if (scratch) {
@@ -735,7 +735,7 @@ int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, fl
     if (rc != ACLGAN_EUNSUPPORTED) return rc;
     rc = ACLGAN_OK;
     if (dw) {
-        rc = conv_wgrad_fast(g, x, dy, dw, db, st);
+        rc = conv_wgrad_fast(g, x, dy, dw, db, st, scratch);
         if (rc == ACLGAN_OK) db = nullptr;   // bias gradient fused into the tuned kernel
         if (rc == ACLGAN_EUNSUPPORTED) {
             if (g.Co > 64) rc = launch_wgrad<2, 2, 2, 2>(g, p, st);       // 128 x 128

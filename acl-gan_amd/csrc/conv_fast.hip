@@ -597,6 +597,184 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_fast_kernel(WgFP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad, k-contiguous LDS layout + ordered slices (Cout % 64 == 0, Cin % 64 == 0; the tuned path of all heavy layers).
+// What changed relative to conv_wgrad_fast_kernel above (profiles/r01: MFMA pipe 68 % busy, fragments fetched with 64
+// ds_read_b32 per k-tile because both operands arrive pixel-major while the MFMA wants 8 consecutive k = pixels per lane):
+//   * a staging thread loads 4 pixels x 4 channels (4 coalesced dwordx4 loads), transposes them in registers and writes
+//     4 b128 rows [channel][4 pixels]: the LDS tiles are [row][16+4] exactly like the forward kernel's, fragments are
+//     b128 reads (16 per k-tile instead of 64 b32), the main loop is the forward's;
+//   * rows are stored interleaved (LDS row (ch%4)*(rows/4) + ch/4) so that the 32 lanes of a write hit consecutive rows;
+//   * no atomics: slices store their tile + bias sums, wgrad_finish_kernel adds them in order (conv_fast_common.h);
+//   * a slice walks its pixel range in sub-chunks of <= 1024 pixels (gather table in LDS), so the slice count is free.
+// ------------------------------------------------------------------------------------------
+constexpr int WGKC_TARGET = 768;     // workgroups in flight the split plan aims for (3 per CU fit: LDS)
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_kc_kernel(WgFP p, WgPartX xp) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && BM + BN <= NT, "one staging unit (4 channels x 4 pixels) per thread, wave-uniform roles");
+    constexpr int CH = 1024;                   // pixels per sub-chunk
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+    __shared__ int2 pinfo[CH + BK];            // per sub-chunk pixel: .x = source pixel of this workgroup's tap, .y = dy pixel
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = xcd_map(blockIdx.x, p.nwg);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int pbeg = blockIdx.z * p.chunk;
+    const int pend = min(p.P, pbeg + p.chunk);
+    const int phase = p.phases ? (int)blockIdx.y : 0;
+    float* dwbase = p.dw + (size_t)phase * p.Co * p.Kn;
+    const int py = phase >> 1, px = phase & 1;
+    const int st_tap = n0 / p.Ci, st_ky = st_tap / p.k, st_kx = st_tap - st_ky * p.k;   // the whole N tile lies inside ONE filter tap
+
+    const bool isA = tid < BM, isB = !isA && tid < BM + BN;
+    const int u = isA ? tid : tid - BM;
+    const int ncg = (isA ? BM : BN) >> 2;           // channel groups of the tile
+    const int cg = u % ncg, pg = u / ncg;           // pg in 0..3: pixels 4pg .. 4pg+3 of the k-tile
+    const float* src = isA ? p.dy : p.x;
+    const int cstride = isA ? p.Co : p.Ci;
+    const int chan = isA ? m0 + 4 * cg : (n0 - st_tap * p.Ci) + 4 * cg;
+    float* mytile = isA ? As : Bs;
+    const int tstride = (isA ? BM : BN) * LDK;
+    f32x4 rr[4];
+    float zm[4];
+    const bool do_bias = p.db != nullptr && (tile % p.tiles_n) == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int cb = pbeg; cb < pend; cb += CH) {
+        const int ce = min(pend, cb + CH);
+        for (int i = tid; i < ce - cb + BK; i += NT) {     // + BK: the clamped tail tile reads past the end
+            int b, oy, ox;
+            wg_coord(p, min(cb + i, ce - 1), b, oy, ox);
+            const int dyp = p.phases ? (b * p.Hf + 2 * (oy + 1) + py) * p.Wf + 2 * (ox + 1) + px : (b * p.Ho + oy) * p.Wo + ox;
+            const int iy = refl(oy * p.s - p.p + st_ky, p.Hu) >> p.up, ix = refl(ox * p.s - p.p + st_kx, p.Wu) >> p.up;
+            pinfo[i] = make_int2(b * p.Hi * p.Wi + iy * p.Wi + ix, dyp);
+        }
+        __syncthreads();
+
+        auto fetch = [&](int kt) __attribute__((always_inline)) {
+            const int pb = kt * BK + 4 * pg;    // sub-chunk relative
+            if (isA || isB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int2 pi = pinfo[pb + j];
+                    rr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
+                    zm[j] = cb + pb + j < ce ? 1.f : 0.f;     // pixels past the sub-chunk contribute nothing; applied in stage()
+                }
+            }
+        };
+        auto stage = [&](int buf, bool real) __attribute__((always_inline)) {
+            if (isA || isB) {
+                float* t = mytile + buf * tstride;
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = rr[j] * zm[j];
+                if (isA) {
+                    const float on = real ? 1.f : 0.f;      // the clamped tail re-stages the last tile: count it once
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bsum += v[j] * on;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 k4 = {v[0][c], v[1][c], v[2][c], v[3][c]};
+                    *reinterpret_cast<f32x4*>(t + (c * ncg + cg) * LDK + 4 * pg) = k4;     // channel 4cg+c -> row c*ncg + cg
+                }
+            }
+        };
+        ACL_GEMM_MAINLOOP(TM, TN, true, true, 0, (ce - cb + BK - 1) / BK, As, Bs, BM * LDK, BN * LDK, LDK, LDK, wm * TM * 32, wn * TN * 32);
+    }
+
+    const bool partial = xp.part != nullptr;
+    if (do_bias) {   // block-uniform; the main loop ended with a barrier, LDS is free
+        float* red = smem;   // [4 pixel groups][BM]
+        if (isA) *reinterpret_cast<f32x4*>(red + pg * BM + 4 * cg) = bsum;
+        __syncthreads();
+        if (tid < BM) {
+            const float t = red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid];
+            if (partial) xp.part_b[((size_t)blockIdx.z * xp.ny + phase) * p.Co + m0 + tid] = t;
+            else p.db[m0 + tid] += t;          // single slice: this workgroup is the only writer of these channels
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    constexpr int MQ = BM / 4, NQ = BN / 4;
+    if (partial) {
+        float* pt = xp.part + (((size_t)blockIdx.z * xp.ny + phase) * p.nwg + tile) * (BM * BN);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rw = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pt[rw * BN + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];      // fragment order: 128-byte coalesced rows
+                }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cr = wn * TN * 32 + j * 32 + l31;
+        const int n = n0 + 4 * (cr % NQ) + cr / NQ;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + 4 * (rw % MQ) + rw / MQ;
+                dwbase[(size_t)m * p.Kn + n] += acc[i][j][r];
+            }
+        }
+    }
+}
+
+bool wgrad_kc_ok(const ConvGeom& g) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ACLGAN_NOWGKC"); off = (e && atoi(e)) ? 1 : 0; }
+    return !off && g.Co % 64 == 0 && g.Ci % 64 == 0;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_wgrad_kc(const ConvGeom& g, WgFP p, void* part, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int ny = p.phases ? 4 : 1;
+    const WgPlan q = wgrad_plan(g.Co, p.Ci, p.Kn, p.P, ny, BK, WGKC_TARGET);
+    if (q.BM != BM || q.BN != BN) { set_error("wgrad_kc: tile plan mismatch"); return ACLGAN_EINVAL; }
+    p.tiles_n = q.tiles_n; p.nwg = q.nwg; p.chunk = q.chunk;
+    WgPartX xp;
+    xp.ny = ny; xp.part = nullptr; xp.part_b = nullptr;
+    const bool use_part = q.splits > 1 || ny > 1;
+    if (use_part) {
+        if (!part) { set_error("wgrad_kc: %d slices need the scratch buffer", q.splits); return ACLGAN_EINVAL; }
+        xp.part = (float*)part;
+        xp.part_b = xp.part + (size_t)q.splits * ny * q.nwg * BM * BN;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kc_kernel<WM, WN, TM, TN>), dim3(p.nwg, ny, q.splits), dim3(WM * WN * 64), 0, st, p, xp);
+    ACL_CHECK_LAUNCH("conv_wgrad_kc_kernel");
+    if (use_part) {
+        const int64_t n = (int64_t)ny * g.Co * (p.Kn / 4);
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, p, xp, BM, BN, q.splits);
+        ACL_CHECK_LAUNCH("wgrad_finish_kernel");
+    }
+    return ACLGAN_OK;
+}
+int launch_wgrad_kc_any(const ConvGeom& g, const WgFP& p, void* part, hipStream_t st) {
+    if (g.Co % 128 == 0 && p.Ci % 128 == 0) return launch_wgrad_kc<2, 2, 2, 2>(g, p, part, st);   // 128 x 128
+    if (g.Co % 128 == 0) return launch_wgrad_kc<2, 2, 2, 1>(g, p, part, st);                       // 128 x 64 (Cin = 64)
+    if (p.Ci % 128 == 0) return launch_wgrad_kc<2, 2, 1, 2>(g, p, part, st);                       // 64 x 128 (Cout = 64)
+    return launch_wgrad_kc<2, 2, 1, 1>(g, p, part, st);                                            // 64 x 64
+}
+
 template <int WM, int WN, int TM, int TN>
 int launch_wgrad_fast(const ConvGeom& g, WgFP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -659,12 +837,14 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
     const size_t nb = (size_t)4 * g.Co * 9 * g.Ci * sizeof(float);
     hipError_t e = hipMemsetAsync(dwp, 0, nb, st);
     if (e != hipSuccess) return hip_fail(e, "memset dwp");
+    const bool kc = wgrad_kc_ok(g);
+    void* part = (char*)dwp + up5_dwp_bytes(g);      // partial tiles of the ordered-slice kernels follow the phase gradients
     WgFP p;
     p.x = x; p.dy = dy; p.dw = dwp; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.Co = g.Co; p.k = 3; p.s = 1; p.p = 0;
     p.up = 0; p.Hu = g.Hi; p.Wu = g.Wi; p.P = g.B * p.Ho * p.Wo; p.Kn = 9 * g.Ci; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
     p.B = g.B; p.ring = 0; p.phases = 1; p.Hf = g.Ho; p.Wf = g.Wo;
-    int rc = launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
+    int rc = kc ? launch_wgrad_kc_any(g, p, part, st) : launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
     if (rc) return rc;
     // (2) fold the 4 x 3x3 phase gradients back onto the 5x5 filter
     const int64_t ns = (int64_t)g.Co * 25 * (g.Ci / 4);
@@ -675,7 +855,7 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ho = g.Ho; p.Wo = g.Wo; p.k = 5; p.s = 1; p.p = 2; p.up = 1; p.Hu = g.Hu; p.Wu = g.Wu;
     p.ring = 2; p.phases = 0; p.Kn = g.K;
     p.P = g.B * (g.Ho * g.Wo - (g.Ho - 4) * (g.Wo - 4));
-    return launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
+    return kc ? launch_wgrad_kc_any(g, p, part, st) : launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -715,6 +895,13 @@ int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, i
 
 size_t conv_up5_scratch_bytes(const ConvGeom& g) {
     return up5_eligible(g) ? (size_t)4 * g.Co * 9 * g.Ci * sizeof(float) : 0;
+}
+// weight-gradient scratch of the tuned kernels: phase gradients of the sub-pixel layers + the partial tiles of the
+// ordered-slice kernel (0 when neither applies)
+size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g) {
+    if (!fast_enabled()) return 0;
+    if (wgrad_kc_ok(g)) return wgrad_part_scratch(g, BK, WGKC_TARGET);
+    return conv_up5_scratch_bytes(g);
 }
 // forward scratch: merged phase weights + ring split-K partials (sub-pixel layers), or the split-K partials of a small-grid layer
 size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g) {
@@ -781,13 +968,16 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
     return dgrad_fast_all<4, 1, 2, 1>(g, p, dxp, dx, accumulate, direct, st);
 }
 
-int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st) {
+int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
     if (!fast_enabled() || g.Co % 4 != 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     WgFP p;
     p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.P = g.M; p.Kn = g.K; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
     p.B = g.B; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
+    // with a scratch buffer (always, inside the engine): k-contiguous tiles + ordered slices, reproducible bit for bit;
+    // the scratch-less operator call keeps the atomics kernel
+    if (wgrad_kc_ok(g) && (scratch || wgrad_part_scratch(g, BK, WGKC_TARGET) == 0)) return launch_wgrad_kc_any(g, p, scratch, st);
     if (g.Co > 64) return launch_wgrad_fast<2, 2, 2, 2>(g, p, st);
     if (g.Co > 32) return launch_wgrad_fast<2, 2, 1, 2>(g, p, st);
     return launch_wgrad_fast<1, 4, 1, 2>(g, p, st);

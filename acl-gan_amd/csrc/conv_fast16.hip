@@ -31,6 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 8 packed 16
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+constexpr int WG16_TARGET = 512; // wgrad workgroups in flight the split plan aims for: one resident round at 2 per CU
 constexpr int BK16 = 32;        // k values per tile of the wgrad kernel (KS = 2) and the unit of the split-K plans
 constexpr int LDQ = 5;          // KS = 2: LDS row stride in u32x4 units: 4 chunks of 8 halfs + 1 pad = 80 bytes
 // forward / dgrad are templated on KS = k-steps (of 16) per tile: KS = 4 (64-deep tiles, row stride 9 x 16 = 144 bytes,
@@ -401,14 +402,8 @@ int launch_dgrad16(const ConvGeom& g, DgFP p, hipStream_t st) {
 // with one slice the tile is added straight into dw; with several, every slice stores its tile (and its bias column
 // sums) to scratch and wgrad16_finish_kernel adds the slices in ORDER -- the weight gradient is reproducible bit for bit.
 // ------------------------------------------------------------------------------------------
-struct Wg16X {          // extras of the 16-bit kernel on top of WgFP
-    float* part;        // [slice][phase][tile][BM][BN] partial tiles in MFMA-fragment row/column order (nullptr: single slice)
-    float* part_b;      // [slice][phase][Co] partial bias sums
-    int ny;
-};
-
 template <class T, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, Wg16X xp) {
+__global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, WgPartX xp) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     static_assert(BM % 64 == 0 && BN % 64 == 0 && BM + BN <= NT, "one staging unit (4 channels x 8 pixels) per thread, wave-uniform roles");
     constexpr int CH = 1024;                   // pixels per sub-chunk
@@ -537,62 +532,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, Wg16
     }
 }
 
-// dw[phase][m][n..n+3] += sum over slices (in order) of the partial tiles; db[m] += sum over slices and phases
-__global__ void wgrad16_finish_kernel(WgFP p, Wg16X xp, int BM, int BN, int splits) {
-    const int MQ = BM / 4, NQ = BN / 4, N4 = p.Kn >> 2;
-    const int64_t n = (int64_t)xp.ny * p.Co * N4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int n4 = (int)(i % N4);
-        int64_t t = i / N4;
-        const int m = (int)(t % p.Co), phase = (int)(t / p.Co);
-        const int tm = m / BM, ml = m - tm * BM, tn = (n4 * 4) / BN, nl = n4 * 4 - tn * BN;
-        const int rw = (ml & 3) * MQ + (ml >> 2), q = nl >> 2;
-        const int tile = tm * p.tiles_n + tn;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < splits; ++z) {
-            const float* pt = xp.part + (((size_t)z * xp.ny + phase) * p.nwg + tile) * ((size_t)BM * BN) + (size_t)rw * BN + q;
-            s[0] += pt[0]; s[1] += pt[NQ]; s[2] += pt[2 * NQ]; s[3] += pt[3 * NQ];
-        }
-        f32x4* o = reinterpret_cast<f32x4*>(p.dw + ((size_t)phase * p.Co + m) * p.Kn + n4 * 4);
-        *o += s;
-    }
-    if (p.db)
-        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.Co; m += gridDim.x * 256) {
-            float s = 0.f;
-            for (int z = 0; z < splits; ++z)
-                for (int ph = 0; ph < xp.ny; ++ph) s += xp.part_b[((size_t)z * xp.ny + ph) * p.Co + m];
-            p.db[m] += s;
-        }
-}
-
-// tile shape and split plan of a wgrad launch (shared by the launcher and the scratch-size query)
-struct Wg16Plan { int BM, BN, tiles_n, nwg, splits, chunk; };
-Wg16Plan wgrad16_plan(int Co, int Ci, int Kn, int P, int ny) {
-    Wg16Plan q;
-    q.BM = Co % 128 == 0 ? 128 : 64;
-    q.BN = Ci % 128 == 0 ? 128 : 64;
-    q.tiles_n = Kn / q.BN;
-    q.nwg = (Co / q.BM) * q.tiles_n;
-    const int target = 512;                                  // one resident round at 2 workgroups per CU
-    int splits = std::max(1, target / (q.nwg * ny));
-    splits = std::max(1, std::min(splits, cdiv(P, 512)));    // a slice is at least 16 k-tiles deep
-    q.chunk = cdiv(cdiv(P, splits), BK16) * BK16;
-    q.splits = cdiv(P, q.chunk);
-    return q;
-}
-size_t wgrad16_partial_bytes(const Wg16Plan& q, int Co, int ny) {
-    if (q.splits <= 1 && ny == 1) return 0;      // (phase launches always go through the partials: 4 phases share one db)
-    return ((size_t)q.splits * ny * q.nwg * q.BM * q.BN + (size_t)q.splits * ny * Co) * sizeof(float);
-}
-
 template <class T, int WM, int WN, int TM, int TN>
 int launch_wgrad16(const ConvGeom& g, WgFP p, void* part, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int ny = p.phases ? 4 : 1;
-    const Wg16Plan q = wgrad16_plan(g.Co, p.Ci, p.Kn, p.P, ny);
+    const WgPlan q = wgrad_plan(g.Co, p.Ci, p.Kn, p.P, ny, BK16, WG16_TARGET);
     if (q.BM != BM || q.BN != BN) { set_error("wgrad16: tile plan mismatch"); return ACLGAN_EINVAL; }
     p.tiles_n = q.tiles_n; p.nwg = q.nwg; p.chunk = q.chunk;
-    Wg16X xp;
+    WgPartX xp;
     xp.ny = ny; xp.part = nullptr; xp.part_b = nullptr;
     const bool use_part = q.splits > 1 || ny > 1;
     if (use_part) {
@@ -604,8 +551,8 @@ int launch_wgrad16(const ConvGeom& g, WgFP p, void* part, hipStream_t st) {
     ACL_CHECK_LAUNCH("conv_wgrad16_kernel");
     if (use_part) {
         const int64_t n = (int64_t)ny * g.Co * (p.Kn / 4);
-        hipLaunchKernelGGL(wgrad16_finish_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, p, xp, BM, BN, q.splits);
-        ACL_CHECK_LAUNCH("wgrad16_finish_kernel");
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, p, xp, BM, BN, q.splits);
+        ACL_CHECK_LAUNCH("wgrad_finish_kernel");
     }
     return ACLGAN_OK;
 }
@@ -823,18 +770,7 @@ WgFP wg_params(const ConvGeom& g, const float* x, const float* dy, float* dw, fl
     return p;
 }
 
-// up5 scratch: [dwp: 4 x Cout x 9 x Cin fp32][partial tiles of the phase launch, reused by the ring launch]
-size_t up5_dwp_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * sizeof(float) + 255) & ~(size_t)255; }
-int up5_ring_pixels(const ConvGeom& g) { return g.B * (g.Ho * g.Wo - (g.Ho - 4) * (g.Wo - 4)); }
-
-size_t wgrad16_scratch(const ConvGeom& g) {
-    if (up5_eligible(g)) {
-        const Wg16Plan a = wgrad16_plan(g.Co, g.Ci, 9 * g.Ci, g.B * (g.Hi - 2) * (g.Wi - 2), 4);
-        const Wg16Plan b = wgrad16_plan(g.Co, g.Ci, g.K, up5_ring_pixels(g), 1);
-        return up5_dwp_bytes(g) + std::max(wgrad16_partial_bytes(a, g.Co, 4), wgrad16_partial_bytes(b, g.Co, 1));
-    }
-    return wgrad16_partial_bytes(wgrad16_plan(g.Co, g.Ci, g.K, g.M, 1), g.Co, 1);
-}
+size_t wgrad16_scratch(const ConvGeom& g) { return wgrad_part_scratch(g, BK16, WG16_TARGET); }
 
 template <class T>
 int wgrad16_t(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {

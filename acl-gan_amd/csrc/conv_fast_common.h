@@ -291,5 +291,78 @@ bool fast_enabled() {
     return v == 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// split-K weight gradients WITHOUT atomics (conv_fast.hip: conv_wgrad_kc_kernel, conv_fast16.hip: conv_wgrad16_kernel):
+// every slice stores its [BM][BN] tile in MFMA-fragment row/column order (128-byte coalesced rows) plus its bias column
+// sums; wgrad_finish_kernel adds the slices in ORDER into dw / db -> the weight gradient is reproducible bit for bit.
+// Tile rows are interleaved: LDS row r of a tile with R rows holds channel 4*(r % (R/4)) + r / (R/4) (the staging threads
+// transpose 4 channels x n pixels in registers and consecutive lanes must hit consecutive LDS rows).
+// ------------------------------------------------------------------------------------------
+struct WgPartX {
+    float* part;        // [slice][phase][tile][BM][BN] partial tiles (nullptr: single slice, tile added straight into dw)
+    float* part_b;      // [slice][phase][Co] partial bias sums
+    int ny;             // phases (4: sub-pixel launch, else 1)
+};
+
+// dw[phase][m][n..n+3] += sum over slices (in order) of the partial tiles; db[m] += sum over slices and phases
+__global__ void wgrad_finish_kernel(WgFP p, WgPartX xp, int BM, int BN, int splits) {
+    const int MQ = BM / 4, NQ = BN / 4, N4 = p.Kn >> 2;
+    const int64_t n = (int64_t)xp.ny * p.Co * N4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int n4 = (int)(i % N4);
+        int64_t t = i / N4;
+        const int m = (int)(t % p.Co), phase = (int)(t / p.Co);
+        const int tm = m / BM, ml = m - tm * BM, tn = (n4 * 4) / BN, nl = n4 * 4 - tn * BN;
+        const int rw = (ml & 3) * MQ + (ml >> 2), q = nl >> 2;
+        const int tile = tm * p.tiles_n + tn;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splits; ++z) {
+            const float* pt = xp.part + (((size_t)z * xp.ny + phase) * p.nwg + tile) * ((size_t)BM * BN) + (size_t)rw * BN + q;
+            s[0] += pt[0]; s[1] += pt[NQ]; s[2] += pt[2 * NQ]; s[3] += pt[3 * NQ];
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(p.dw + ((size_t)phase * p.Co + m) * p.Kn + n4 * 4);
+        *o += s;
+    }
+    if (p.db)
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.Co; m += gridDim.x * 256) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z)
+                for (int ph = 0; ph < xp.ny; ++ph) s += xp.part_b[((size_t)z * xp.ny + ph) * p.Co + m];
+            p.db[m] += s;
+        }
+}
+
+// tile shape and split plan of such a launch (shared by the launchers and the scratch-size queries).
+// bk: pixels per k-tile (16 fp32 / 32 16-bit); target: workgroups in flight the launch aims for
+struct WgPlan { int BM, BN, tiles_n, nwg, splits, chunk; };
+static WgPlan wgrad_plan(int Co, int Ci, int Kn, int P, int ny, int bk, int target) {
+    WgPlan q;
+    q.BM = Co % 128 == 0 ? 128 : 64;
+    q.BN = Ci % 128 == 0 ? 128 : 64;
+    q.tiles_n = Kn / q.BN;
+    q.nwg = (Co / q.BM) * q.tiles_n;
+    int splits = std::max(1, target / (q.nwg * ny));
+    splits = std::max(1, std::min(splits, cdiv(P, 512)));    // a slice is at least 512 pixels deep
+    q.chunk = cdiv(cdiv(P, splits), bk) * bk;
+    q.splits = cdiv(P, q.chunk);
+    return q;
+}
+static size_t wgrad_partial_bytes(const WgPlan& q, int Co, int ny) {
+    if (q.splits <= 1 && ny == 1) return 0;      // (phase launches always go through the partials: 4 phases share one db)
+    return ((size_t)q.splits * ny * q.nwg * q.BM * q.BN + (size_t)q.splits * ny * Co) * sizeof(float);
+}
+static size_t up5_dwp_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * sizeof(float) + 255) & ~(size_t)255; }
+static int up5_ring_pixels(const ConvGeom& g) { return g.B * (g.Ho * g.Wo - (g.Ho - 4) * (g.Wo - 4)); }
+// scratch of a partial-store weight gradient of layer g: [dwp (sub-pixel layers)][partials]
+static size_t wgrad_part_scratch(const ConvGeom& g, int bk, int target) {
+    if (up5_eligible(g)) {
+        const WgPlan a = wgrad_plan(g.Co, g.Ci, 9 * g.Ci, g.B * (g.Hi - 2) * (g.Wi - 2), 4, bk, target);
+        const WgPlan b = wgrad_plan(g.Co, g.Ci, g.K, up5_ring_pixels(g), 1, bk, target);
+        return up5_dwp_bytes(g) + std::max(wgrad_partial_bytes(a, g.Co, 4), wgrad_partial_bytes(b, g.Co, 1));
+    }
+    return wgrad_partial_bytes(wgrad_plan(g.Co, g.Ci, g.K, g.M, 1, bk, target), g.Co, 1);
+}
+
+
 }  // namespace
 }  // namespace aclgan

@@ -94,6 +94,9 @@ struct aclgan_ctx {
     int trained = -1;          // group whose gradients this step produces (-1: forward only)
     bool fire_dry = false;     // aclgan_bucket_schedule: invoke the bucket callback during a dry run
     // data-parallel gradient buckets (aclgan_set_grad_buckets / aclgan_set_bucket_callback)
+    aclgan_sync_fn sync_fn = nullptr;   // forward sync point of gen_update (global-batch focus sums), aclgan_set_forward_sync
+    void* sync_user = nullptr;
+    int sync_world = 1;
     int64_t bucket_elems = 0;
     aclgan_bucket_fn bucket_fn = nullptr;
     void* bucket_user = nullptr;
@@ -746,16 +749,26 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         {dB4, ACLGAN_L_GEN_FOCUS_B_SIZE, ACLGAN_L_GEN_FOCUS_B_DIGIT},
         {dA4, ACLGAN_L_GEN_FOCUS_A_SIZE, ACLGAN_L_GEN_FOCUS_A_DIGIT},
         {dA24, ACLGAN_L_GEN_FOCUS_A2_SIZE, ACLGAN_L_GEN_FOCUS_A2_DIGIT}};
-    for (int i = 0; i < 3; ++i) {
-        RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, hp.focus_upper, sums + (size_t)i * nfs, c.st));
-        RUN(focus_loss_finish(fl[i].a->d, npix, sums + (size_t)i * nfs, hp.focus_delta, hp.focus_upper, hp.focus_lower, hp.focus_epsilon, fscale,
-                              L + fl[i].size_slot, L + fl[i].digit_slot, fl[i].a->g, c.st, c.lscale));
+    // data parallelism with the reference's GLOBAL-batch semantics of the focus losses (trainer.py:149-161: the size loss
+    // squares a sum over the whole batch): the 6 sums are all-reduced by the caller at a forward sync point, every rank
+    // then differentiates relu(T_global)^2 through its own pixels; the gradient keeps the LOCAL 1/(H W b 3) scale because
+    // the gradient all-reduce averages over ranks
+    float* ftot = nullptr;
+    if (c.sync_fn) { ftot = c.allocf(8); NEED(ftot); }
+    for (int i = 0; i < 3; ++i) RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, hp.focus_upper, sums + (size_t)i * nfs, c.st));
+    if (ftot) {
+        RUN(focus_totals(sums, npix, 3, ftot, c.st));
+        if (!c.dry) c.sync_fn(c.sync_user, ftot, 6);
     }
+    for (int i = 0; i < 3; ++i)
+        RUN(focus_loss_finish(fl[i].a->d, npix, sums + (size_t)i * nfs, hp.focus_delta, hp.focus_upper, hp.focus_lower, hp.focus_epsilon, fscale,
+                              L + fl[i].size_slot, L + fl[i].digit_slot, fl[i].a->g, c.st, c.lscale, ftot ? ftot + 2 * i : nullptr,
+                              npix * (int64_t)c.sync_world));
     // identity losses (trainer.py:162-165)
     RUN(l1_loss(rA4->d, 4, xa->d, npix, L + ACLGAN_L_IDT_A, rA4->g, hp.recon_x_w, 1, c.st, c.lscale));
     RUN(l1_loss(rB4->d, 4, xb->d, npix, L + ACLGAN_L_IDT_B, rB4->g, hp.recon_x_w, 1, c.st, c.lscale));
     if (!c.dry) {
-        hipLaunchKernelGGL(gen_total_kernel, dim3(1), dim3(1), 0, c.st, L, hp, fscale);
+        hipLaunchKernelGGL(gen_total_kernel, dim3(1), dim3(1), 0, c.st, L, hp, ftot ? fscale / (float)c.sync_world : fscale);
         ACL_CHECK_LAUNCH("gen_total_kernel");
     }
     return run_tape(c);   // loss_gen_total.backward() (trainer.py:169)
@@ -977,6 +990,12 @@ int aclgan_dis_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const
     rc = dis_update_impl(*ctx, x_a, x_b, z, B, H, W, *hp, losses);
     ctx->reset_step();
     return rc;
+}
+
+int aclgan_set_forward_sync(aclgan_ctx* ctx, aclgan_sync_fn fn, void* user, int world_size) {
+    ACL_REQUIRE(ctx && world_size >= 1, "bad ctx / world size");
+    ctx->sync_fn = fn; ctx->sync_user = user; ctx->sync_world = fn ? world_size : 1;
+    return ACLGAN_OK;
 }
 
 int aclgan_set_grad_buckets(aclgan_ctx* ctx, int64_t bucket_elems, aclgan_bucket_fn fn, void* user) {

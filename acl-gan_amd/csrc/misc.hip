@@ -458,18 +458,21 @@ int focus_sums(const float* dec4, int64_t npix, float eps, float upper, float* p
     ACL_CHECK_LAUNCH("focus_sums_kernel");
     return ACLGAN_OK;
 }
+// totals (optional): [0] = sum(m - upper), [1] = digit sum over npix_total pixels -- the sums of the GLOBAL batch, all-reduced
+// by the caller (data parallelism with the reference's global-batch semantics of the size loss, trainer.py:149-157)
 __global__ void focus_finish_kernel(const float4* __restrict__ dec4, int64_t npix, const float* __restrict__ part, int nblk, float delta,
                                     float upper, float lower, float eps, float scale, float* size_slot, float* digit_slot,
-                                    float4* __restrict__ d_dec4, const float* __restrict__ lscale) {
+                                    float4* __restrict__ d_dec4, const float* __restrict__ lscale, const float* __restrict__ totals, int64_t npix_total) {
     __shared__ double tot[2];
     if (threadIdx.x < 2) {       // every workgroup repeats the same ordered sum of <= 512 partials
         double t = 0.0;
-        for (int b = 0; b < nblk; ++b) t += (double)part[2 * b + threadIdx.x];
+        if (totals) t = (double)totals[threadIdx.x];
+        else for (int b = 0; b < nblk; ++b) t += (double)part[2 * b + threadIdx.x];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
     const double D = tot[0];                                   // sum(m - upper)
-    const float hi = (float)fmax(D, 0.0), lo = (float)fmax((double)npix * ((double)lower - (double)upper) - D, 0.0);
+    const float hi = (float)fmax(D, 0.0), lo = (float)fmax((double)npix_total * ((double)lower - (double)upper) - D, 0.0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *size_slot = delta * (hi * hi + lo * lo);
         *digit_slot = (float)tot[1];
@@ -486,10 +489,25 @@ __global__ void focus_finish_kernel(const float4* __restrict__ dec4, int64_t npi
     }
 }
 int focus_loss_finish(const float* dec4, int64_t npix, const float* part, float delta, float upper, float lower, float eps, float scale,
-                      float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st, const float* lscale) {
+                      float* size_slot, float* digit_slot, float* d_dec4, hipStream_t st, const float* lscale, const float* totals, int64_t npix_total) {
     hipLaunchKernelGGL(focus_finish_kernel, dim3((int)std::min<int64_t>(cdiv64(npix, 256), 1024)), dim3(256), 0, st, (const float4*)dec4, npix, part,
-                       focus_sums_blocks(npix), delta, upper, lower, eps, scale, size_slot, digit_slot, (float4*)d_dec4, lscale);
+                       focus_sums_blocks(npix), delta, upper, lower, eps, scale, size_slot, digit_slot, (float4*)d_dec4, lscale, totals,
+                       totals ? npix_total : npix);
     ACL_CHECK_LAUNCH("focus_finish_kernel");
+    return ACLGAN_OK;
+}
+// ordered sums of the per-workgroup partials of `nmask` masks: totals[2*i + {0,1}] (one tiny launch)
+__global__ void focus_totals_kernel(const float* __restrict__ part, int nblk, int nmask, float* __restrict__ totals) {
+    const int t = threadIdx.x;
+    if (t >= 2 * nmask) return;
+    const float* p = part + (size_t)(t >> 1) * 2 * nblk;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)p[2 * b + (t & 1)];
+    totals[t] = (float)s;
+}
+int focus_totals(const float* part, int64_t npix, int nmask, float* totals, hipStream_t st) {
+    hipLaunchKernelGGL(focus_totals_kernel, dim3(1), dim3(64), 0, st, part, focus_sums_blocks(npix), nmask, totals);
+    ACL_CHECK_LAUNCH("focus_totals_kernel");
     return ACLGAN_OK;
 }
 

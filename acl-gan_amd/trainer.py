@@ -268,7 +268,43 @@ class aclgan_Trainer:
         except Exception:
             pass
 
-    # ---- plumbing ----
+    # ---- plumbing: the nn.Module surface of the reference class (trainer.py:14) that callers can reach ----
+    NETS = ("gen_AB", "gen_BA", "dis_A", "dis_B", "dis_2")
+
+    def state_dict(self):
+        """the reference trainer's own state_dict(): '<net>.<key>' for the five networks, in registration order
+        (254 entries: tests/golden/state_dict_keys.txt)"""
+        sd = OrderedDict()
+        for n in self.NETS:
+            for k, v in getattr(self, n).state_dict().items():
+                sd[n + "." + k] = v
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        known = set()
+        for n in self.NETS:
+            sub = OrderedDict((k[len(n) + 1:], v) for k, v in sd.items() if k.startswith(n + "."))
+            known.update(n + "." + k for k in sub)
+            getattr(self, n).load_state_dict(sub, strict=strict)
+        extra = [k for k in sd if k not in known]
+        if strict and extra:
+            raise L.AclganError("load_state_dict: unexpected keys %s" % extra[:5])
+
+    def named_parameters(self):
+        for n in self.NETS:
+            for k, v in getattr(self, n).named_parameters():
+                yield n + "." + k, v
+
+    def parameters(self):
+        return [p for _, p in self.named_parameters()]
+
+    def zero_grad(self):
+        for grp in (L.GROUP_GEN, L.GROUP_DIS):
+            self._grad[grp].zero_()
+
+    def to(self, *a, **k):
+        return self
+
     def cuda(self, *a, **k):
         return self
 
@@ -302,6 +338,10 @@ class aclgan_Trainer:
                         elif kind == "xavier":
                             fan_out = v.shape[0] * int(math.prod(v.shape[2:]))
                             w = torch.randn(tuple(v.shape)) * math.sqrt(2.0) * math.sqrt(2.0 / (fan_in + fan_out))
+                        elif kind == "orthogonal":     # utils.py:285-286
+                            w = torch.nn.init.orthogonal_(torch.empty(tuple(v.shape)), gain=math.sqrt(2.0))
+                        elif kind == "default":        # utils.py:287-288: nn.Conv2d / nn.Linear's own reset_parameters() stays
+                            w = torch.nn.init.kaiming_uniform_(torch.empty(tuple(v.shape)), a=math.sqrt(5.0))
                         else:
                             raise L.AclganError("Unsupported initialization: %s" % kind)
                         v.copy_(w.to(self.device))
@@ -378,6 +418,8 @@ class aclgan_Trainer:
             if self._reducer is not None:
                 self._reducer.begin(grp)
             L.check(fn(self._ctx, L.ptr(x_a), L.ptr(x_b), L.ptr(zz), B, H, W, C.byref(hpc), L.ptr(self._losses), st), which + "_update")
+            if getattr(self, "_sync_error", None) is not None:
+                raise self._sync_error
             self._allreduce_grads(grp)
             o = self._opt[grp]
             o["steps"] += 1
@@ -417,6 +459,19 @@ class aclgan_Trainer:
         self._zgen = torch.Generator().manual_seed(torch.initial_seed() + dist.get_rank())
         if os.environ.get("ACLGAN_DDP_OVERLAP", "1") != "0":
             self._reducer = BucketReducer(self._ctx, lambda g: self._grad[g], world)
+        # optional: the reference's global-batch semantics of the focus losses (config key ddp_global_focus / env
+        # ACLGAN_DDP_GLOBAL_FOCUS=1): the 6 mask sums are all-reduced at a forward sync point of gen_update
+        if self._hp.get("ddp_global_focus", False) or os.environ.get("ACLGAN_DDP_GLOBAL_FOCUS") == "1":
+            def on_sync(user, ptr, n):
+                try:
+                    off = int(ptr) - self._ws.data_ptr()
+                    t = self._ws[off: off + 4 * n].view(torch.float32)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)      # stream-ordered: the compute stream waits for it, the host does not
+                except BaseException as e:   # noqa: BLE001  (must not unwind through the C frames)
+                    self._sync_error = e
+            self._sync_error = None
+            self._sync_cb = L.SYNC_FN(on_sync)
+            L.check(L.lib.aclgan_set_forward_sync(self._ctx, self._sync_cb, None, world), "set_forward_sync")
 
     def _allreduce_grads(self, grp):
         """Average the flat gradient buffer over ranks with RCCL before Adam.  With the bucket reducer the collectives

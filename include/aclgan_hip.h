@@ -177,6 +177,15 @@ int aclgan_set_grad_buckets(aclgan_ctx* ctx, int64_t bucket_elems, aclgan_bucket
  * scheduler (no GPU work; usable on a CPU-only host): order[0..count).  fire != 0 also invokes the callback. */
 int aclgan_bucket_schedule(aclgan_ctx* ctx, int group, int B, int H, int W, int fire, int* order, int cap, int* count);
 
+/* Optional forward sync point of aclgan_gen_update for data-parallel runs that want the reference's GLOBAL-batch focus
+ * losses (trainer.py:149-161 squares a sum over the whole batch, which per-rank evaluation + gradient averaging does not
+ * reproduce): after the three masks' sums are on the device, fn(user, sums, 6) is called on the host with the DEVICE
+ * pointer of float[6] = {sum(m - upper), sum 1/(|m-.5|+eps)} x {B, A, A2} (inside the bound workspace); the caller
+ * enqueues a SUM all-reduce over `world_size` ranks on it; the step then uses the reduced values with N = world_size *
+ * local pixels.  The reported focus losses / loss_gen_total become the global-batch values.  fn = NULL switches it off. */
+typedef void (*aclgan_sync_fn)(void* user, float* sums_dev, int n);
+int aclgan_set_forward_sync(aclgan_ctx* ctx, aclgan_sync_fn fn, void* user, int world_size);
+
 /* opt.zero_grad() (trainer.py:91,248) */
 int aclgan_zero_grad(aclgan_ctx* ctx, int group, void* stream);
 /* opt.step() (trainer.py:170,293): one fused kernel over the group's flat buffers; `step` is the
@@ -296,6 +305,10 @@ int aclgan_l1_loss(const float* a, int a_channels, const float* b, int64_t npix,
  * *size_slot = delta*(relu(sum(m-upper))^2 + relu(sum(lower-m))^2), *digit_slot = sum 1/(|m-0.5|+eps);
  * d_dec4 (may be NULL) ch3 += scale * d(size+digit)/d ch3.  scratch: aclgan_focus_loss_scratch_bytes(npix). */
 size_t aclgan_focus_loss_scratch_bytes(int64_t npix);
+/* the same with the two sums supplied by the caller (device float[2]: sum(m - upper), digit sum over npix_total pixels):
+ * one shard of a larger batch -- see aclgan_set_forward_sync */
+int aclgan_focus_loss_global(const float* dec4, int64_t npix, const float* totals, int64_t npix_total, float delta, float upper,
+                             float lower, float eps, float scale, float* size_slot, float* digit_slot, float* d_dec4, void* stream);
 int aclgan_focus_loss(const float* dec4, int64_t npix, float delta, float upper, float lower, float eps, float scale,
                       float* size_slot, float* digit_slot, float* d_dec4, void* scratch, void* stream);
 

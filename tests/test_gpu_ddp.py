@@ -22,3 +22,51 @@ def test_allreduce_flat_rccl_world1():
         assert torch.equal(x, ref)
     finally:
         dist.destroy_process_group()
+
+
+def test_trainer_data_parallel_world1():
+    """The whole N>1 trainer path on one GPU (RCCL world size 1, ACLGAN_BENCH_FORCE_DIST=1): rank-0 broadcast of
+    parameters / Adam state, the engine's bucket callback driving overlapped all-reduces, the forward sync point of the
+    global-batch focus losses -- results must equal the plain single-GPU trainer's."""
+    import torch.distributed as dist
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd.trainer import aclgan_Trainer
+    from oracle import aclgan_oracle as O
+    cfg = O.default_config()
+    cfg["gen"].update(dim=8, mlp_dim=16, n_res=1); cfg["dis"].update(dim=8); cfg["display_size"] = 1
+    nets = O.test_nets(cfg, 0)
+    g = torch.Generator().manual_seed(31)
+    x_a = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    x_b = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    z = [torch.randn(2, 8, 1, 1, generator=g) for _ in range(6)]
+
+    def run(tr):
+        for n in O.OracleTrainer.NETS:
+            getattr(tr, n).load_state_dict(nets[n], strict=False)
+        tr.dis_update(x_a, x_b, cfg, z=z[:3])
+        tr.gen_update(x_a, x_b, cfg, z=z[3:])
+        torch.cuda.synchronize()
+        # (gradients, not parameters: Adam's first step is lr * g / (|g| + eps), so an element whose gradient is ~0 may land
+        #  on either side by 2 lr depending on fp32 summation order)
+        return tr._grad[0].clone(), tr._grad[1].clone(), tr._losses.clone()
+    ref = run(aclgan_Trainer(cfg))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29900 + os.getpid() % 300)
+    os.environ["ACLGAN_BENCH_FORCE_DIST"] = "1"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg2 = dict(cfg); cfg2["ddp_global_focus"] = True
+        tr = aclgan_Trainer(cfg2)
+        assert tr._reducer is not None and tr._zgen is not None
+        got = run(tr)
+        nb = [(tr._grad[g_].numel() + tr._reducer.bucket_elems - 1) // tr._reducer.bucket_elems for g_ in (0, 1)]
+        assert sorted(tr._reducer.order) == list(range(nb[0]))          # the last update was gen_update: every bucket reduced once
+        for a, b in zip(got, ref):
+            assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item())
+        os.environ["ACLGAN_DDP_OVERLAP"] = "0"                          # the post-backward path gives the same result
+        got2 = run(aclgan_Trainer(cfg2))
+        for a, b in zip(got2, ref):
+            assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item())
+    finally:
+        os.environ.pop("ACLGAN_BENCH_FORCE_DIST", None); os.environ.pop("ACLGAN_DDP_OVERLAP", None)
+        dist.destroy_process_group()

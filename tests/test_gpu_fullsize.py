@@ -105,7 +105,7 @@ def _forward_and_losses(T, B, S):
     for n, v in list(Ld.items()) + list(Lg.items()):
         v = float(v)
         got = ld[n] if n in ld else lg[n]
-        tol = 2e-2 if n.endswith("_size") else LTOL
+        tol = 5e-3 if n.endswith("_size") else LTOL
         errs[n] = (abs(got - v) / max(1e-3, abs(v)), tol, got, v)
     print("loss rel errors:", {k: "%.2e" % e[0] for k, e in errs.items()})
     bad = {k: e for k, e in errs.items() if not e[0] <= e[1]}
@@ -134,7 +134,7 @@ def _step_gradients(T, B, S):
     og = O.OracleTrainer(cfg, nets=nets); og.gen_update(x_a, x_b, z[3:], apply=False)
     for n, v in list(od.losses.items()) + list(og.losses.items()):
         got = float(getattr(trd if n.startswith("loss_dis") else trg, n))
-        assert abs(got - v) <= (2e-2 if n.endswith("_size") else LTOL) * max(1e-3, abs(v)), (n, got, v)
+        assert abs(got - v) <= (5e-3 if n.endswith("_size") else LTOL) * max(1e-3, abs(v)), (n, got, v)
     worst = []
     for tr, orc, nets_ in ((trd, od, ("dis_A", "dis_B", "dis_2")), (trg, og, ("gen_AB", "gen_BA"))):
         gmax = max(float(t.grad.norm()) for n in nets_ for t in orc.nets[n].values())

@@ -107,6 +107,11 @@ def test_conv_wgrad(L, case):
     dw, db = gpu_conv_wgrad(L, d, nhwc(x).cuda(), nhwc(dy).cuda())
     assert rel_err(dw, ohwi(w.grad)) < TOL
     assert rel_err(db, b.grad) < TOL
+    if Co % 64 == 0 and Ci % 64 == 0:
+        # heavy layers: k-contiguous tiles + ordered slices (csrc/conv_fast.hip: conv_wgrad_kc_kernel) -- no atomics, so the
+        # weight and bias gradients are reproducible bit for bit
+        dw3, db3 = gpu_conv_wgrad(L, d, nhwc(x).cuda(), nhwc(dy).cuda())
+        assert torch.equal(dw, dw3) and torch.equal(db, db3)
     if L.lib.aclgan_conv2d_wgrad_scratch_bytes(C.byref(d)):   # the scratch-less variant of the same layer (exact gather / atomics) must agree
         dw2, db2 = gpu_conv_wgrad(L, d, nhwc(x).cuda(), nhwc(dy).cuda(), ws=False)
         assert rel_err(dw2, ohwi(w.grad)) < TOL and rel_err(db2, b.grad) < TOL

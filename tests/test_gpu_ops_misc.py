@@ -206,6 +206,30 @@ def test_focus_loss(L, npix, shift):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_focus_loss_global_shards(L):
+    """data parallelism with global-batch semantics (aclgan_set_forward_sync): each shard, given the all-reduced sums,
+    reports the full batch's losses and produces the full batch's gradient rows."""
+    from gpu_util import rel_err
+    g = torch.Generator().manual_seed(9)
+    npix = 2 * 4096
+    dec = torch.tanh(torch.randn(npix, 4, generator=g) * 0.5 + 0.6).cuda()       # mask mean high: the relu branch is active
+    scale = 0.025 / npix / 3
+    scr = torch.empty(L.lib.aclgan_focus_loss_scratch_bytes(npix) // 4 + 16, device="cuda")
+    full_slots = torch.zeros(2, device="cuda"); full_d = torch.zeros(npix, 4, device="cuda")
+    L.check(L.lib.aclgan_focus_loss(L.ptr(dec), npix, 0.001, 0.5, 0.3, 0.01, scale, L.ptr(full_slots), C.c_void_p(full_slots.data_ptr() + 4),
+                                    L.ptr(full_d), L.ptr(scr), L.stream_ptr()))
+    m = (dec[:, 3].double() + 1) / 2
+    totals = torch.tensor([float((m - 0.5).sum()), float((1 / ((m - 0.5).abs() + 0.01)).sum())], device="cuda")
+    for r in range(2):
+        shard = dec[r * 4096:(r + 1) * 4096].contiguous()
+        slots = torch.zeros(2, device="cuda"); d = torch.zeros(4096, 4, device="cuda")
+        L.check(L.lib.aclgan_focus_loss_global(L.ptr(shard), 4096, L.ptr(totals), npix, 0.001, 0.5, 0.3, 0.01, scale, L.ptr(slots),
+                                               C.c_void_p(slots.data_ptr() + 4), L.ptr(d), L.stream_ptr()), "focus_loss_global")
+        assert rel_err(slots, full_slots) < 1e-5
+        assert rel_err(d, full_d[r * 4096:(r + 1) * 4096]) < 1e-5
+        assert float(full_slots[0]) > 0
+
+
 # ---------------------------------------------------------------------------------------------
 # reference-generated operator vectors, replayed on the HIP path
 # ---------------------------------------------------------------------------------------------

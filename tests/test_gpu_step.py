@@ -55,6 +55,24 @@ def test_state_dict_surface(T):
     for k, v in tr.gen_AB.state_dict().items():
         if k in nets["gen_AB"]:
             assert torch.equal(v.cpu(), nets["gen_AB"][k]), k
+    # trainer-level nn.Module surface: state_dict() / load_state_dict() / parameters() with the reference's 254 keys
+    full = tr.state_dict()
+    assert [(k.split(".", 1)[0], k.split(".", 1)[1], tuple(v.shape)) for k, v in full.items()] == \
+           [(net, key, shp) for net in O.OracleTrainer.NETS for key, shp in want[net]]
+    assert len(full) == 254 and len(tr.parameters()) == 222 and sum(p.numel() for p in tr.parameters()) == 30058648 + 24822729
+    tr2 = T.aclgan_Trainer(cfg)
+    tr2.load_state_dict(full)
+    assert torch.equal(tr2._param[0], tr._param[0]) and torch.equal(tr2._param[1], tr._param[1])
+    with pytest.raises(T.L.AclganError):
+        tr2.load_state_dict({"bogus.weight": torch.zeros(1)})
+    # the other init kinds of utils.py:279-288
+    for kind, check in (("orthogonal", lambda w: (w.reshape(w.shape[0], -1) @ w.reshape(w.shape[0], -1).T - 2 * torch.eye(w.shape[0], device=w.device)).abs().max() < 1e-3),
+                        ("default", lambda w: abs(float(w.abs().max()) - (1.0 / (w.shape[1] * 16)) ** 0.5) < 1e-3),
+                        ("gaussian", lambda w: abs(float(w.std()) - 0.02) < 1e-3)):
+        c2 = dict(cfg); c2["init"] = kind
+        tk = T.aclgan_Trainer(c2)
+        assert check(dict(tk.gen_BA.named_parameters())["enc_content.model.2.conv.weight"].contiguous()), kind
+        assert float(dict(tk.gen_BA.named_parameters())["enc_content.model.2.conv.bias"].abs().max()) == 0.0
     # init statistics (utils.py:274-294, trainer.py:49-52)
     w = dict(tr.gen_BA.named_parameters())["enc_content.model.2.conv.weight"]
     assert abs(float(w.std()) - (2.0 / (128 * 16)) ** 0.5) < 2e-3
@@ -126,7 +144,7 @@ def test_update_steps_match_reference(T, fix, ltol, gtol):
 
     for n, v in meta["losses"].items():
         got = float(getattr(trd if n.startswith("loss_dis") else trg, n))
-        tol = 2e-2 if n.endswith("_size") else ltol
+        tol = 5e-3 if n.endswith("_size") else ltol    # centred, ordered summation (misc.hip: focus_sums_kernel)
         assert abs(got - v) <= tol * max(1e-3, abs(v)), (n, got, v)
 
     gmax = max(v[1] for v in meta["grad_stats"].values())
@@ -185,7 +203,7 @@ def test_chained_steps_and_lr_schedule(T):
     tr.dis_update(x_a, x_b, cfg, z=z[:3])
     tr.gen_update(x_a, x_b, cfg, z=z[3:6])
     for n, v in meta["seq_losses"].items():
-        tol = 5e-2 if n.endswith("_size") else 2e-3
+        tol = 5e-3 if n.endswith("_size") else 2e-3
         assert abs(float(getattr(tr, n)) - v) <= tol * max(1e-3, abs(v)), n
     assert tr._current_lr(cfg) == cfg["lr"]
     tr.update_learning_rate()
@@ -283,7 +301,7 @@ def test_non_square_odd_batch_step_matches_oracle(T):
     og = O.OracleTrainer(cfg, nets=nets); og.gen_update(x_a, x_b, z[3:], apply=False)
     for n, v in list(od.losses.items()) + list(og.losses.items()):
         got = float(getattr(trd if n.startswith("loss_dis") else trg, n))
-        assert abs(got - v) <= (2e-2 if n.endswith("_size") else 1e-3) * max(1e-3, abs(v)), (n, got, v)
+        assert abs(got - v) <= (5e-3 if n.endswith("_size") else 1e-3) * max(1e-3, abs(v)), (n, got, v)
     for tr, orc, nets_ in ((trd, od, ("dis_A", "dis_B", "dis_2")), (trg, og, ("gen_AB", "gen_BA"))):
         gmax = max(float(t.grad.norm()) for n in nets_ for t in orc.nets[n].values())
         for n in nets_:
@@ -312,7 +330,7 @@ def test_step_at_sizes_divisible_by_4_only(T):
     og = O.OracleTrainer(cfg, nets=nets); og.gen_update(x_a, x_b, z[3:], apply=False)
     for n, v in list(od.losses.items()) + list(og.losses.items()):
         got = float(getattr(trd if n.startswith("loss_dis") else trg, n))
-        assert abs(got - v) <= (2e-2 if n.endswith("_size") else 1e-3) * max(1e-3, abs(v)), (n, got, v)
+        assert abs(got - v) <= (5e-3 if n.endswith("_size") else 1e-3) * max(1e-3, abs(v)), (n, got, v)
     for tr, orc, nets_ in ((trd, od, ("dis_A", "dis_B", "dis_2")), (trg, og, ("gen_AB", "gen_BA"))):
         gmax = max(float(t.grad.norm()) for n in nets_ for t in orc.nets[n].values())
         for n in nets_:
