@@ -244,7 +244,7 @@ int launch_fwd16(const ConvGeom& g, FwdFP p, hipStream_t st) {
 // dgrad (Cout % 32 == 0, Cin % 32 == 0): interior rows straight into dx, halo ring mirrored in with atomics
 // ------------------------------------------------------------------------------------------
 template <class T, int KS, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
+__global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int NCH = 2 * KS, LDQ = NCH + 1, BKT = 16 * KS;
     constexpr int RP = NT / NCH;
@@ -256,8 +256,15 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = xcd_map(blockIdx.x, p.nwg);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int tile = xcd_map(blockIdx.x, pk.nwg);
+    int m0 = (tile / pk.tiles_n) * BM;
+    const int n0 = (tile % pk.tiles_n) * BN;
+    DgFP p = pk;                               // local copy: mode 3 resolves to 1 (interior tile) or 2 (halo tile) per workgroup
+    if (pk.mode == 3) {
+        const int tm = tile / pk.tiles_n;
+        if (tm >= pk.Ti) { p.mode = 2; m0 = (tm - pk.Ti) * BM; } else p.mode = 1;
+    }
+    const bool merged = pk.mode == 3;
     const int cls = blockIdx.z / p.ksplit, slice = blockIdx.z - cls * p.ksplit;
     const int cy = cls / p.s, cx = cls % p.s;
     const int Tx = (p.k - cx + p.s - 1) / p.s, Ty = (p.k - cy + p.s - 1) / p.s;
@@ -271,7 +278,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
             const int py = y2 * p.s + cy, px = x2 * p.s + cx;
             if (py < p.Hp && px < p.Wp) {
                 if (p.mode == 0) oo = (b * p.Hp + py) * p.Wp + px;
-                else oo = (b * p.Hd + (refl(py - p.pad, p.Hi) >> p.upshift)) * p.Wd + (refl(px - p.pad, p.Wi) >> p.upshift);
+                else oo = (b * p.Hd + (refl(py - p.pad, p.Hi) >> p.upshift)) * p.Wd + (refl(px - p.pad, p.Wi) >> p.upshift);   // mode 1: identity inside
+                // merged launch: interior pixels that also receive mirrored halo rows are combined with atomics (bit 30)
+                if (merged && p.mode == 1 && (dg_is_target(py - p.pad, p.Hi, p.pad) || dg_is_target(px - p.pad, p.Wi, p.pad))) oo |= 1 << 30;
             }
         }
         ri_o[r] = oo;
@@ -354,10 +363,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int oo = ri_o[wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-                if (oo >= 0) {
+                const int of = ri_o[wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                if (of >= 0) {
+                    const int oo = of & ~(1 << 30);
                     float* o = p.dxp + (size_t)oo * p.Ci + n;
-                    if (p.ksplit > 1 || p.mode == 2) atomicAdd(o, acc[i][j][r]);   // split-K partials / mirrored halo
+                    if (p.ksplit > 1 || p.mode == 2 || (of >> 30)) atomicAdd(o, acc[i][j][r]);   // split-K partials / mirrored halo / its targets
                     else if (p.accumulate) *o += acc[i][j][r];
                     else *o = acc[i][j][r];
                 }
@@ -393,6 +403,41 @@ int launch_dgrad16(const ConvGeom& g, DgFP p, hipStream_t st) {
     }
     hipLaunchKernelGGL((conv_dgrad16_kernel<T, KS, WM, WN, TM, TN>), dim3(p.nwg, 1, g.s * g.s * p.ksplit), dim3(WM * WN * 64), 0, st, p);
     ACL_CHECK_LAUNCH("conv_dgrad16_kernel");
+    return ACLGAN_OK;
+}
+
+// interior + halo ring in ONE launch (mode 3; see launch_dgrad_fast_merged in conv_fast.hip)
+template <class T, int KS, int WM, int WN, int TM, int TN>
+int launch_dgrad16_merged(const ConvGeom& g, DgFP p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    // OPT-IN (ACLGAN_MERGEDHALO=1).  Measured (profiles/r02_experiments.md): correct, but slower -- the 34 halo tiles are a second,
+    // nearly empty round after the 512 interior workgroups (one full tile duration of tail), and the divergent atomic/plain
+    // epilogue of the interior tiles costs more than the 36-48 us launch it removes: fp32 step 171.7 -> 182.5 ms.
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ACLGAN_MERGEDHALO"); off = (e && atoi(e)) ? 0 : 1; }
+    if (off || g.p == 0) return ACLGAN_EUNSUPPORTED;
+    int mi = 0, mh = 0;
+    for (int cy = 0; cy < g.s; ++cy)
+        for (int cx = 0; cx < g.s; ++cx) {
+            const int ylo = g.p > cy ? (g.p - cy + g.s - 1) / g.s : 0, xlo = g.p > cx ? (g.p - cx + g.s - 1) / g.s : 0;
+            const int yhi = std::min(p.Hc - 1, (g.p + g.Hi - 1 - cy) / g.s), xhi = std::min(p.Wc - 1, (g.p + g.Wi - 1 - cx) / g.s);
+            const int inner = std::max(0, yhi - ylo + 1) * std::max(0, xhi - xlo + 1);
+            mi = std::max(mi, g.B * inner); mh = std::max(mh, g.B * (p.Hc * p.Wc - inner));
+        }
+    if (mi <= 0 || mh <= 0) return ACLGAN_EUNSUPPORTED;
+    p.tiles_n = cdiv(g.Ci, BN);
+    p.Ti = cdiv(mi, BM);
+    p.nwg = (p.Ti + cdiv(mh, BM)) * p.tiles_n;
+    const int nk_min = ((g.k + g.s - 1) / g.s) * ((g.k + g.s - 1) / g.s) * (g.Co / (16 * KS));
+    if (p.nwg * g.s * g.s < 128 && nk_min * KS >= 32) return ACLGAN_EUNSUPPORTED;       // small grid: split-K pays more
+    p.ksplit = 1; p.mode = 3; p.Mc = mi;
+    if (!p.accumulate) {
+        const int64_t n = (int64_t)g.B * (2 * g.p * g.Wi + 2 * g.p * g.Hi) * (g.Ci / 4);
+        hipLaunchKernelGGL(dg_frame_zero_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 2048)), dim3(256), 0, st, p.dxp, g.B, g.Hi, g.Wi, g.Ci, g.p);
+        ACL_CHECK_LAUNCH("dg_frame_zero_kernel");
+    }
+    hipLaunchKernelGGL((conv_dgrad16_kernel<T, KS, WM, WN, TM, TN>), dim3(p.nwg, 1, g.s * g.s), dim3(WM * WN * 64), 0, st, p);
+    ACL_CHECK_LAUNCH("conv_dgrad16_kernel(merged)");
     return ACLGAN_OK;
 }
 
@@ -677,6 +722,16 @@ int launch_dgrad16_ks(const ConvGeom& g, const DgFP& p, hipStream_t st) {
     if (g.Ci > 64) return launch_dgrad16<T, KS, 2, 2, 2, 2>(g, p, st);
     return launch_dgrad16<T, KS, 4, 1, 2, 2>(g, p, st);
 }
+template <class T, int KS>
+int launch_dgrad16_merged_ks(const ConvGeom& g, const DgFP& p, hipStream_t st) {
+    if (g.Ci % 256 == 0 && wide_tiles()) return launch_dgrad16_merged<T, KS, 2, 4, 2, 2>(g, p, st);
+    if (g.Ci > 64) return launch_dgrad16_merged<T, KS, 2, 2, 2, 2>(g, p, st);
+    return launch_dgrad16_merged<T, KS, 4, 1, 2, 2>(g, p, st);
+}
+template <class T>
+int launch_dgrad16_merged_any(const ConvGeom& g, const DgFP& p, hipStream_t st) {
+    return (p.Co % 64 == 0 && g.Ci > 64) ? launch_dgrad16_merged_ks<T, 4>(g, p, st) : launch_dgrad16_merged_ks<T, 2>(g, p, st);
+}
 template <class T>
 int launch_dgrad16_any(const ConvGeom& g, const DgFP& p, hipStream_t st) {
     return (p.Co % 64 == 0 && g.Ci > 64) ? launch_dgrad16_ks<T, 4>(g, p, st) : launch_dgrad16_ks<T, 2>(g, p, st);
@@ -754,8 +809,11 @@ int dgrad16_t(const ConvGeom& g, const float* dy, const float* w, const u16* w16
     }
     // interior positions straight into dx, then the halo ring mirrored in: together = dgrad + reflection_pad2d backward
     DgFP p = dg_params(g, dy, w16t, dx);
-    p.mode = 1; p.accumulate = accumulate;
-    int rc = launch_dgrad16_any<T>(g, p, st);
+    p.accumulate = accumulate;
+    int rc = launch_dgrad16_merged_any<T>(g, p, st);        // one launch: interior tiles + halo tiles
+    if (rc != ACLGAN_EUNSUPPORTED) return rc;
+    p.mode = 1;
+    rc = launch_dgrad16_any<T>(g, p, st);
     if (rc) return rc;
     if (g.p > 0) { p.mode = 2; rc = launch_dgrad16_any<T>(g, p, st); }
     return rc;

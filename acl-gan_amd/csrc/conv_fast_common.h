@@ -161,7 +161,29 @@ struct DgFP {
     //            targets are folded through reflect + >>upshift into the Hd x Wd low-res dx
     int dyv, py, px, Hf, Wf, band, upshift, Hd, Wd;
     const unsigned short* w16t;  // 16-bit kernels: weights transposed to [tap][cin][cout] (cout contiguous = the GEMM k axis of dgrad)
+    // mode 3 = interior AND halo in ONE launch: M-tiles [0, Ti) enumerate the interior rows (mode 1), tiles [Ti, ..) the halo
+    // ring (mode 2).  Interior pixels that are mirror targets of the reflection are combined with atomics by both kinds of
+    // tile (the caller zeroes that frame first unless it accumulates); all other pixels keep plain stores.
+    int Ti;
 };
+
+// image rows / columns that receive mirrored halo gradients (reflection pad p on a size-n axis): padded -j -> j, n-1+j -> n-1-j
+__host__ __device__ __forceinline__ bool dg_is_target(int i, int n, int p) { return (i >= 1 && i <= p) || (i >= n - 1 - p && i <= n - 2); }
+
+// zero the mirror-target frame of dx [B][H][W][C] (rows 1..p, H-1-p..H-2 full width; columns likewise full height)
+__global__ void dg_frame_zero_kernel(float* __restrict__ dx, int B, int H, int W, int C, int p) {
+    const int C4 = C >> 2, per = 2 * p * W + 2 * p * H;
+    const int64_t n = (int64_t)B * per * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t t = i / C4;
+        const int j = (int)(t % per), b = (int)(t / per);
+        int y, x;
+        if (j < 2 * p * W) { const int r = j / W; y = r < p ? 1 + r : H - 1 - p + (r - p); x = j - r * W; }
+        else { const int jj = j - 2 * p * W, cc = jj / H; x = cc < p ? 1 + cc : W - 1 - p + (cc - p); y = jj - cc * H; }
+        *reinterpret_cast<f32x4*>(dx + ((size_t)(b * H + y) * W + x) * C + c4 * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
 
 // class-grid box of the interior positions for parity class (cy, cx)
 __device__ __forceinline__ void dg_box(const DgFP& p, int cy, int cx, int& ylo, int& yhi, int& xlo, int& xhi) {
