@@ -100,6 +100,7 @@ SIGNATURES = {
     "aclgan_conv16_eligible": (ci, [C.POINTER(ConvDesc), ci]),
     "aclgan_pack_weights16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "aclgan_conv2d_fwd16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp, vp]),
+    "aclgan_conv2d_fwd16_x16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp, vp]),
     "aclgan_conv2d_dgrad16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp, vp]),
     "aclgan_conv2d_wgrad16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp]),
     "aclgan_conv2d_fwd16_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),

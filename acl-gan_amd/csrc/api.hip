@@ -118,6 +118,16 @@ int aclgan_conv2d_fwd16(const aclgan_conv_desc* d, int dtype, const float* x, co
     if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_fwd16: no 16-bit kernel for this shape (Cin, Cout must be multiples of 32)");
     return rc;
 }
+int aclgan_conv2d_fwd16_x16(const aclgan_conv_desc* d, int dtype, const void* x16, const float* w, const void* w16, const float* bias, float* y,
+                            void* scratch, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(x16 && w16 && y, "conv2d_fwd16_x16: null buffer");
+    rc = conv_fwd16(g, dtype, nullptr, w, w16, bias, y, scratch, (hipStream_t)stream, x16);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_fwd16_x16: no 16-bit kernel for this shape (Cin, Cout must be multiples of 32)");
+    return rc;
+}
 int aclgan_conv2d_dgrad16(const aclgan_conv_desc* d, int dtype, const float* dy, const float* w, const void* w16t, float* dx, int accumulate,
                           void* scratch, void* stream) {
     ConvGeom g;

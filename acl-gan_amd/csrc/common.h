@@ -65,7 +65,9 @@ size_t conv_fwd16_scratch_bytes(const ConvGeom& g);
 size_t conv_dgrad16_scratch_bytes(const ConvGeom& g);
 size_t conv_wgrad16_scratch_bytes(const ConvGeom& g);
 // w: fp32 OHWI master weights (only read by the sub-pixel path, to merge the phase filters before rounding); w16: OHWI 16-bit pack
-int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st);
+// x16 (optional): the producer's 16-bit copy of x (same layout) -- read instead of x, same result
+int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st,
+               const void* x16 = nullptr);
 // w16t: 16-bit pack transposed to [tap][cin][cout]; dx is complete on return (interior + mirrored halo)
 int conv_dgrad16(const ConvGeom& g, int dtype, const float* dy, const float* w, const void* w16t, float* dx, int accumulate, void* scratch, hipStream_t st);
 int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);

@@ -262,6 +262,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
     constexpr int B_IT = (BK * NVB + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM * LDK + BK * LDB)];
     __shared__ int ri_o[BM];
+    // halo launches (mode 2): most filter taps see no valid output pixel from a ring row (top strip: only ty <= py ...), so the
+    // workgroup first collects the taps that matter for ITS rows and loops over those only (3 of 9 for a 3x3 strip tile)
+    __shared__ unsigned long long tap_mask;
+    __shared__ int tap_list[64];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDK;
 
@@ -283,10 +287,24 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
 
     int ylo, yhi, xlo, xhi;
     dg_box(p, cy, cx, ylo, yhi, xlo, xhi);
+    const bool compact = p.mode == 2 && Ty * Tx <= 64;
+    if (tid == 0) tap_mask = 0ull;
+    __syncthreads();
     for (int r = tid; r < BM; r += NT) {
         int oo = -1, b, y2, x2;
         if (dg_row(p, m0 + r, ylo, yhi, xlo, xhi, b, y2, x2)) {
             const int py = y2 * p.s + cy, px = x2 * p.s + cx;
+            if (compact && py < p.Hp && px < p.Wp) {
+                unsigned long long mk = 0ull;
+                for (int t = 0; t < Ty * Tx; ++t) {
+                    const int ty = t / Tx, tx = t - ty * Tx;
+                    const int oy = y2 - ty, ox = x2 - tx;
+                    bool ok = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+                    if (p.band > 0) ok = ok && (oy < 2 || oy >= p.Ho - 2 || ox < 2 || ox >= p.Wo - 2);
+                    if (ok) mk |= 1ull << t;
+                }
+                if (mk) atomicOr(&tap_mask, mk);
+            }
             if (py < p.Hp && px < p.Wp) {
                 if (p.mode == 0) oo = (b * p.Hp + py) * p.Wp + px;
                 else oo = (b * p.Hd + (refl(py - p.pad, p.Hi) >> p.upshift)) * p.Wd + (refl(px - p.pad, p.Wi) >> p.upshift);   // mode 1: identity inside
@@ -295,6 +313,19 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
             }
         }
         ri_o[r] = oo;
+    }
+    int ntap = Ty * Tx;
+    if (compact) {
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int t = 0; t < Ty * Tx; ++t)
+                if ((tap_mask >> t) & 1ull) tap_list[n++] = t;
+            tap_list[63] = n;
+        }
+        __syncthreads();
+        ntap = tap_list[63];
+        if (ntap == 0) return;           // no row of this tile receives anything (block-uniform)
     }
     int ay[A_IT], ax[A_IT], ab[A_IT];
 #pragma unroll
@@ -319,9 +350,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
     int f_tap = -1, tapoff = 0;
 
     auto fetch = [&](int kt) __attribute__((always_inline)) {
-        const int t = kt / cpt, cc = kt - t * cpt;
-        if (t != f_tap) {
-            f_tap = t;
+        const int tq = kt / cpt, cc = kt - tq * cpt;
+        if (tq != f_tap) {
+            f_tap = tq;
+            const int t = compact ? tap_list[tq] : tq;
             const int ty = t / Tx, tx = t - ty * Tx;
             tapoff = ((cy + p.s * ty) * p.k + (cx + p.s * tx)) * p.Ci;
 #pragma unroll
@@ -370,7 +402,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk_all = Ty * Tx * cpt;
+    const int nk_all = ntap * cpt;
     const int nkz = (nk_all + p.ksplit - 1) / p.ksplit;
     const int kbeg = slice * nkz, nk = min(nkz, nk_all - kbeg);
     if (nk <= 0) return;
@@ -419,7 +451,10 @@ int launch_dgrad_fast(const ConvGeom& g, DgFP p, hipStream_t st) {
     const int nk_min = ((g.k + g.s - 1) / g.s) * ((g.k + g.s - 1) / g.s) * (g.Co / 16);   // k-tiles of the largest parity class
     const int nblk = p.nwg * g.s * g.s;
     p.ksplit = 1;
-    if (nblk < 128 && nk_min >= 32) p.ksplit = max(1, min(nk_min / 8, 512 / nblk));   // floor: stay within one round of 512 resident workgroups
+    // halo launches loop over the useful taps only (about 1 / taps-per-axis of them): plan the slices for that shorter loop --
+    // every slice ends in 128 x 128 fp32 atomics, which is what the old 15-slice halo launch mostly consisted of
+    const int nk_plan = (p.mode == 2 && p.band == 0) ? std::max(g.Co / 16, nk_min / ((g.k + g.s - 1) / g.s)) : nk_min;
+    if (nblk < 128 && nk_plan >= 32) p.ksplit = max(1, min(nk_plan / 8, 512 / nblk));   // floor: stay within one round of 512 resident workgroups
     if (p.ksplit > 1 && p.mode == 0) {
         hipError_t e = hipMemsetAsync(p.dxp, 0, conv_dgrad_scratch_bytes(g), st);
         if (e != hipSuccess) return hip_fail(e, "memset dxp");
@@ -788,6 +823,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_kc_kernel(WgFP p, WgP
     }
 }
 
+// ACLGAN_BIGTILE=1: 256 x 128 workgroup tiles with 8 waves for forward / dgrad of the large layers (25 % fewer operand bytes per
+// MFMA than 128 x 128; one workgroup per CU)
+bool big_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_BIGTILE"); v = (e && atoi(e)) ? 1 : 0; }
+    return v == 1;
+}
+
 bool wgrad_kc_ok(const ConvGeom& g) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("ACLGAN_NOWGKC"); off = (e && atoi(e)) ? 1 : 0; }
@@ -994,6 +1037,7 @@ int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.M = g.M; p.K = g.K; p.act = g.act; p.tiles_n = 0; p.nwg = 0; p.nkz = 0;
     p.B = g.B; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
+    if (g.Co % 128 == 0 && big_tiles() && g.M >= 256 * 128) return launch_fwd_fast<4, 2, 2, 2>(g, p, st);   // 256 x 128, 8 waves (experiment)
     if (g.Co > 64) return launch_fwd_fast<2, 2, 2, 2>(g, p, st);
     if (g.Co > 32) return launch_fwd_fast<4, 1, 2, 2>(g, p, st);
     return launch_fwd_fast<4, 1, 2, 1>(g, p, st);
@@ -1013,6 +1057,7 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
     p.Hc = cdiv(g.Hp, g.s); p.Wc = cdiv(g.Wp, g.s); p.Mc = 0; p.tiles_n = 0; p.nwg = 0; p.ksplit = 1;
     p.mode = 0; p.accumulate = 0; p.pad = g.p; p.B = g.B; p.Hi = g.Hu; p.Wi = g.Wu;
     p.dyv = 0; p.py = 0; p.px = 0; p.Hf = 0; p.Wf = 0; p.band = 0; p.upshift = 0; p.Hd = g.Hu; p.Wd = g.Wu;
+    if (g.Ci % 128 == 0 && big_tiles() && g.M >= 256 * 128) return dgrad_fast_all<4, 2, 2, 2>(g, p, dxp, dx, accumulate, direct, st);
     if (g.Ci > 64) return dgrad_fast_all<2, 2, 2, 2>(g, p, dxp, dx, accumulate, direct, st);
     if (g.Ci > 32) return dgrad_fast_all<4, 1, 2, 2>(g, p, dxp, dx, accumulate, direct, st);
     return dgrad_fast_all<4, 1, 2, 1>(g, p, dxp, dx, accumulate, direct, st);

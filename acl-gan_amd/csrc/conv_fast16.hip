@@ -106,7 +106,9 @@ __device__ __forceinline__ void mfma_step16(const u32x4 (&fa)[TM][KS], const u32
 // ------------------------------------------------------------------------------------------
 // forward (Cin % 32 == 0)
 // ------------------------------------------------------------------------------------------
-template <class T, int KS, int WM, int WN, int TM, int TN>
+// A16: the activations come from the producer's 16-bit copy (p.x16) -- one dwordx4 per 8-k chunk, no conversion -- instead of
+// being read as fp32 and rounded here.  Same values either way (the producer rounds with the same instruction).
+template <class T, int KS, int WM, int WN, int TM, int TN, bool A16>
 __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int NCH = 2 * KS, LDQ = NCH + 1, BKT = 16 * KS;   // chunks (of 8 k) per row, row stride, k values per tile
@@ -147,6 +149,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
     const int cpt = p.Ci / BKT;                // k-tiles per tap
     int aoff[A_IT];
     f32x4 ra[A_IT][2];
+    u32x4 rah[A_IT];
     u32x4 rb[B_IT];
     int f_tap = -1;
 
@@ -164,8 +167,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
         }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const f32x4* s = reinterpret_cast<const f32x4*>(p.x + (size_t)aoff[i] + cc * BKT);
-            ra[i][0] = s[0]; ra[i][1] = s[1];
+            if (A16) rah[i] = *reinterpret_cast<const u32x4*>(p.x16 + (size_t)aoff[i] + cc * BKT);
+            else {
+                const f32x4* s = reinterpret_cast<const f32x4*>(p.x + (size_t)aoff[i] + cc * BKT);
+                ra[i][0] = s[0]; ra[i][1] = s[1];
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
         u32x4* a = As + buf * BM * LDQ;
         u32x4* b = Bs + buf * BN * LDQ;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) a[(r0 + i * RP) * LDQ + q] = pack8<T>(ra[i][0], ra[i][1]);
+        for (int i = 0; i < A_IT; ++i) a[(r0 + i * RP) * LDQ + q] = A16 ? rah[i] : pack8<T>(ra[i][0], ra[i][1]);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             if (BN % RP == 0 || r0 + i * RP < BN) b[(r0 + i * RP) * LDQ + q] = rb[i];
@@ -223,7 +229,8 @@ int launch_fwd16(const ConvGeom& g, FwdFP p, hipStream_t st) {
     const int rows = p.ring > 0 ? p.B * (p.Ho * p.Wo - std::max(0, p.Ho - 2 * p.ring) * std::max(0, p.Wo - 2 * p.ring)) : p.M;
     p.nwg = cdiv(rows, BM) * p.tiles_n;
     if (p.phases) {
-        hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN>), dim3(p.nwg, 1, 4), dim3(WM * WN * 64), 0, st, p);
+        if (p.x16) hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN, true>), dim3(p.nwg, 1, 4), dim3(WM * WN * 64), 0, st, p);
+        else hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN, false>), dim3(p.nwg, 1, 4), dim3(WM * WN * 64), 0, st, p);
         ACL_CHECK_LAUNCH("conv_fwd16_kernel(phases)");
         return ACLGAN_OK;
     }
@@ -231,7 +238,8 @@ int launch_fwd16(const ConvGeom& g, FwdFP p, hipStream_t st) {
     fwd_split_plan(rows, g.Co, g.K, BKT, &splits, &p.nkz);
     p.rows = rows;
     if (splits > 1 && p.part == nullptr) { splits = 1; p.nkz = g.K / BKT; }   // no partial buffer: single pass (never atomics)
-    hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN>), dim3(p.nwg, 1, splits), dim3(WM * WN * 64), 0, st, p);
+    if (p.x16) hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN, true>), dim3(p.nwg, 1, splits), dim3(WM * WN * 64), 0, st, p);
+    else hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN, false>), dim3(p.nwg, 1, splits), dim3(WM * WN * 64), 0, st, p);
     ACL_CHECK_LAUNCH("conv_fwd16_kernel");
     if (splits > 1) {
         hipLaunchKernelGGL(fwd_split_finish_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)rows * std::max(1, g.Co / 4), 256), 4096)), dim3(256), 0, st, p, splits);
@@ -251,6 +259,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
     constexpr int A_IT = BM / RP, B_IT = (BN + RP - 1) / RP;
     __shared__ u32x4 smem[2 * (BM + BN) * LDQ];
     __shared__ int ri_o[BM];
+    // halo launches (mode 2): most filter taps see no valid output pixel from a ring row (top strip: only ty <= py ...), so the
+    // workgroup first collects the taps that matter for ITS rows and loops over those only (3 of 9 for a 3x3 strip tile)
+    __shared__ unsigned long long tap_mask;
+    __shared__ int tap_list[64];
     u32x4* As = smem;
     u32x4* Bs = smem + 2 * BM * LDQ;
 
@@ -272,10 +284,24 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
 
     int ylo, yhi, xlo, xhi;
     dg_box(p, cy, cx, ylo, yhi, xlo, xhi);
+    const bool compact = p.mode == 2 && Ty * Tx <= 64;
+    if (tid == 0) tap_mask = 0ull;
+    __syncthreads();
     for (int r = tid; r < BM; r += NT) {
         int oo = -1, b, y2, x2;
         if (dg_row(p, m0 + r, ylo, yhi, xlo, xhi, b, y2, x2)) {
             const int py = y2 * p.s + cy, px = x2 * p.s + cx;
+            if (compact && py < p.Hp && px < p.Wp) {
+                unsigned long long mk = 0ull;
+                for (int t = 0; t < Ty * Tx; ++t) {
+                    const int ty = t / Tx, tx = t - ty * Tx;
+                    const int oy = y2 - ty, ox = x2 - tx;
+                    bool ok = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+                    if (p.band > 0) ok = ok && (oy < 2 || oy >= p.Ho - 2 || ox < 2 || ox >= p.Wo - 2);
+                    if (ok) mk |= 1ull << t;
+                }
+                if (mk) atomicOr(&tap_mask, mk);
+            }
             if (py < p.Hp && px < p.Wp) {
                 if (p.mode == 0) oo = (b * p.Hp + py) * p.Wp + px;
                 else oo = (b * p.Hd + (refl(py - p.pad, p.Hi) >> p.upshift)) * p.Wd + (refl(px - p.pad, p.Wi) >> p.upshift);   // mode 1: identity inside
@@ -284,6 +310,19 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
             }
         }
         ri_o[r] = oo;
+    }
+    int ntap = Ty * Tx;
+    if (compact) {
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int t = 0; t < Ty * Tx; ++t)
+                if ((tap_mask >> t) & 1ull) tap_list[n++] = t;
+            tap_list[63] = n;
+        }
+        __syncthreads();
+        ntap = tap_list[63];
+        if (ntap == 0) return;           // no row of this tile receives anything (block-uniform)
     }
     int ay[A_IT], ax[A_IT], ab[A_IT];
 #pragma unroll
@@ -304,9 +343,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
     int f_tap = -1, tapoff = 0;
 
     auto fetch = [&](int kt) __attribute__((always_inline)) {
-        const int t = kt / cpt, cc = kt - t * cpt;
-        if (t != f_tap) {
-            f_tap = t;
+        const int tq = kt / cpt, cc = kt - tq * cpt;
+        if (tq != f_tap) {
+            f_tap = tq;
+            const int t = compact ? tap_list[tq] : tq;
             const int ty = t / Tx, tx = t - ty * Tx;
             tapoff = ((cy + p.s * ty) * p.k + (cx + p.s * tx)) * p.Ci * p.Co;
 #pragma unroll
@@ -348,7 +388,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk_all = Ty * Tx * cpt;
+    const int nk_all = ntap * cpt;
     const int nkz = (nk_all + p.ksplit - 1) / p.ksplit;
     const int kbeg = slice * nkz, nk = min(nkz, nk_all - kbeg);
     if (nk <= 0) return;
@@ -396,7 +436,8 @@ int launch_dgrad16(const ConvGeom& g, DgFP p, hipStream_t st) {
     const int nk_min = ((g.k + g.s - 1) / g.s) * ((g.k + g.s - 1) / g.s) * (g.Co / (16 * KS));   // k-tiles of the largest parity class
     const int nblk = p.nwg * g.s * g.s;
     p.ksplit = 1;
-    if (nblk < 128 && nk_min * KS >= 32) p.ksplit = max(1, min(nk_min * KS / 8, 512 / nblk));
+    const int nk_plan = (p.mode == 2 && p.band == 0) ? std::max(g.Co / (16 * KS), nk_min / ((g.k + g.s - 1) / g.s)) : nk_min;   // halo: useful taps only
+    if (nblk < 128 && nk_plan * KS >= 32) p.ksplit = max(1, min(nk_plan * KS / 8, 512 / nblk));
     if (p.ksplit > 1 && p.mode == 1 && !p.accumulate) {
         hipError_t e = hipMemsetAsync(p.dxp, 0, (size_t)g.B * g.Hi * g.Wi * g.Ci * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "memset dx");
@@ -691,9 +732,9 @@ bool wgrad16_ok(const ConvGeom& g) { return fast_enabled() && g.Co % 64 == 0 && 
 
 size_t up5_w16_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * sizeof(u16) + 255) & ~(size_t)255; }
 
-FwdFP fwd_params(const ConvGeom& g, const float* x, const u16* w16, const float* bias, float* y) {
+FwdFP fwd_params(const ConvGeom& g, const float* x, const u16* w16, const float* bias, float* y, const u16* x16 = nullptr) {
     FwdFP p;
-    p.part = nullptr; p.rows = 0; p.w = nullptr; p.w16 = w16;
+    p.part = nullptr; p.rows = 0; p.w = nullptr; p.w16 = w16; p.x16 = x16;
     p.x = x; p.bias = bias; p.y = y;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.M = g.M; p.K = g.K; p.act = g.act; p.tiles_n = 0; p.nwg = 0; p.nkz = 0;
@@ -744,7 +785,7 @@ int launch_wgrad16_any(const ConvGeom& g, const WgFP& p, void* part, hipStream_t
     return launch_wgrad16<T, 2, 2, 1, 1>(g, p, part, st);                                            // 64 x 64: half the threads stage
 }
 template <class T>
-int fwd16_t(const ConvGeom& g, const float* x, const float* w, const u16* w16, const float* bias, float* y, void* scratch, hipStream_t st) {
+int fwd16_t(const ConvGeom& g, const float* x, const u16* x16, const float* w, const u16* w16, const float* bias, float* y, void* scratch, hipStream_t st) {
     if (up5_eligible(g)) {
         if (!scratch || !w) { set_error("conv_fwd16: the upsample+5x5 layer needs its scratch buffer and the fp32 weights"); return ACLGAN_EINVAL; }
         u16* wp = (u16*)scratch;
@@ -752,7 +793,7 @@ int fwd16_t(const ConvGeom& g, const float* x, const float* w, const u16* w16, c
         hipLaunchKernelGGL(up5_merge16_kernel<T>, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, (u16*)nullptr, g.Co, g.Ci);
         ACL_CHECK_LAUNCH("up5_merge16_kernel");
         // (1) the four phases: VALID 3x3 conv on the low-res input with the merged weights
-        FwdFP p = fwd_params(g, x, wp, bias, y);
+        FwdFP p = fwd_params(g, x, wp, bias, y, x16);
         p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.k = 3; p.s = 1; p.p = 0; p.up = 0; p.Hu = g.Hi; p.Wu = g.Wi;
         p.M = g.B * p.Ho * p.Wo; p.K = 9 * g.Ci; p.phases = 1; p.Hf = g.Ho; p.Wf = g.Wo;
         ConvGeom gp = g;
@@ -760,12 +801,12 @@ int fwd16_t(const ConvGeom& g, const float* x, const float* w, const u16* w16, c
         int rc = launch_fwd16_any<T>(gp, p, st);
         if (rc) return rc;
         // (2) the output ring of width 2: exact 5x5 gather (reflection at the borders of the upsampled image)
-        p = fwd_params(g, x, w16, bias, y);
+        p = fwd_params(g, x, w16, bias, y, x16);
         p.ring = 2;
         p.part = (float*)((char*)scratch + up5_w16_bytes(g));
         return launch_fwd16_any<T>(g, p, st);
     }
-    FwdFP p = fwd_params(g, x, w16, bias, y);
+    FwdFP p = fwd_params(g, x, w16, bias, y, x16);
     p.part = (float*)scratch;
     return launch_fwd16_any<T>(g, p, st);
 }
@@ -871,10 +912,11 @@ size_t conv_fwd16_scratch_bytes(const ConvGeom& g) {
 size_t conv_dgrad16_scratch_bytes(const ConvGeom& g) { return dgrad16_ok(g) && up5_eligible(g) ? up5_w16_bytes(g) : 0; }
 size_t conv_wgrad16_scratch_bytes(const ConvGeom& g) { return wgrad16_ok(g) ? wgrad16_scratch(g) : 0; }
 
-int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st) {
+int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st,
+               const void* x16) {
     if (!fwd16_ok(g)) return ACLGAN_EUNSUPPORTED;
-    if (dtype == ACLGAN_DTYPE_BF16) return fwd16_t<PBF16>(g, x, w, (const u16*)w16, bias, y, scratch, st);
-    if (dtype == ACLGAN_DTYPE_FP16) return fwd16_t<PFP16>(g, x, w, (const u16*)w16, bias, y, scratch, st);
+    if (dtype == ACLGAN_DTYPE_BF16) return fwd16_t<PBF16>(g, x, (const u16*)x16, w, (const u16*)w16, bias, y, scratch, st);
+    if (dtype == ACLGAN_DTYPE_FP16) return fwd16_t<PFP16>(g, x, (const u16*)x16, w, (const u16*)w16, bias, y, scratch, st);
     set_error("conv_fwd16: dtype %d", dtype);
     return ACLGAN_EINVAL;
 }

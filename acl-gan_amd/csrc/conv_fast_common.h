@@ -59,6 +59,7 @@ struct FwdFP {
     // fwd_split_finish_kernel adds the slices in ORDER (+ bias, activation): bit-reproducible, unlike the atomics path
     float* part; int rows;
     const unsigned short* w16;   // 16-bit kernels: OHWI weights (or merged phase weights) as bf16 / fp16 bit patterns
+    const unsigned short* x16;   // 16-bit kernels, optional: the input already rounded to the 16-bit type by its producer (same NHWC layout)
 };
 
 __device__ __forceinline__ bool fwd_row(const FwdFP& p, int m, int& b, int& oy, int& ox) {

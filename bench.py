@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch; default: 8 (BASELINE configs[1], [2]), 32 with --dtype fp16 (configs[4]: 256 over 8 GPUs)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="compute dtype of the heavy convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -176,6 +176,8 @@ def main():
         cpu_baseline_worker()
         return
 
+    if args.batch is None:
+        args.batch = 32 if args.dtype == "fp16" else 8
     t_start = time.perf_counter()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -186,6 +188,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback for the product path")
+    # test hooks: ACLGAN_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and ACLGAN_DIST_BACKEND=gloo replaces RCCL (which refuses two
+    # ranks on one device), so that the complete N>1 control flow can be exercised on a 1-GPU box (tests/test_gpu_ddp.py)
+    if os.environ.get("ACLGAN_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit("rank %d: local GPU %d not visible (%d devices)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -194,7 +200,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ACLGAN_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import aclgan_amd  # noqa: F401  (raises if libaclgan_hip.so is missing)
     from aclgan_amd import _lib as L
@@ -245,6 +255,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses_ok = all(map(lambda n: torch.isfinite(getattr(tr, n)).item(), ["loss_gen_total", "loss_dis_total"]))
+    replicas_identical = None
+    if use_dist:      # (outside the timed region) data-parallel replicas must still hold identical parameters after K steps
+        chk = torch.stack([tr._param[0].double().sum(), tr._param[1].double().sum(), tr._param[0].double().abs().sum()])
+        lst = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(lst, chk)
+        replicas_identical = all(bool(torch.equal(lst[0], x)) for x in lst)
 
     # secondary figure: the reference loop's cadence D_update=1, G_update=2 -> B / (t_dis + t_gen / 2);
     # two extra steps OUTSIDE the timed region, split with events between the two updates
@@ -271,6 +287,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic U(-1,1) A/B batches, reference init statistics, seeded z",
             "config": {"workload": "%s %dx%d %s, batch=%d per GPU: dis_update + gen_update (fwd+bwd+Adam each)" % (name, S, S, args.dtype, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                       "dist_backend": dist.get_backend() if use_dist else None, "replicas_identical": replicas_identical,
                        "grad_allreduce": ("overlapped with backward (bucket callback)" if getattr(tr, "_reducer", None) is not None else
                                           ("after backward" if use_dist else "none (1 GPU)")),
                        "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),

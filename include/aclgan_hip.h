@@ -238,6 +238,10 @@ int aclgan_pack_weights16(const float* w, void* w16, void* w16t, int Co, int tap
  * NULL).  scratch: aclgan_conv2d_*16_scratch_bytes (NULL allowed when that is 0) */
 int aclgan_conv2d_fwd16(const aclgan_conv_desc* d, int dtype, const float* x, const float* w, const void* w16,
                         const float* bias, float* y, void* scratch, void* stream);
+/* forward with the input ALREADY rounded to the 16-bit type by its producer (x16: same NHWC layout, bf16 / fp16 bit patterns;
+ * aclgan_pack_weights16(x, x16, NULL, B*H*W, 1, C, ...) makes one): half the activation bytes, no conversion, same result bit for bit */
+int aclgan_conv2d_fwd16_x16(const aclgan_conv_desc* d, int dtype, const void* x16, const float* w, const void* w16,
+                            const float* bias, float* y, void* scratch, void* stream);
 int aclgan_conv2d_dgrad16(const aclgan_conv_desc* d, int dtype, const float* dy, const float* w, const void* w16t,
                           float* dx, int accumulate, void* scratch, void* stream);
 int aclgan_conv2d_wgrad16(const aclgan_conv_desc* d, int dtype, const float* x, const float* dy, float* dw,

@@ -19,10 +19,13 @@ L.check(L.lib.aclgan_pack_weights16(L.ptr(w), L.ptr(w16), L.ptr(w16t), Co, k * k
 nb = max(L.lib.aclgan_conv2d_fwd16_scratch_bytes(C.byref(d)), L.lib.aclgan_conv2d_dgrad16_scratch_bytes(C.byref(d)),
          L.lib.aclgan_conv2d_wgrad16_scratch_bytes(C.byref(d)))
 scr = torch.empty(nb // 4 + 64, device="cuda")
+x16 = torch.empty(x.numel(), dtype=torch.int16, device="cuda")
+L.check(L.lib.aclgan_pack_weights16(L.ptr(x), L.ptr(x16), None, B * Hi * Hi, 1, Ci, dt, st))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(8):
     if it == 3: e0.record()
-    if which == "fwd": L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), dt, L.ptr(x), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), L.ptr(scr), st))
+    if which == "fwdx16": L.check(L.lib.aclgan_conv2d_fwd16_x16(C.byref(d), dt, L.ptr(x16), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), L.ptr(scr), st))
+    elif which == "fwd": L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), dt, L.ptr(x), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), L.ptr(scr), st))
     elif which == "dgrad": L.check(L.lib.aclgan_conv2d_dgrad16(C.byref(d), dt, L.ptr(dy), L.ptr(w), L.ptr(w16t), L.ptr(dx), 0, L.ptr(scr), st))
     else: L.check(L.lib.aclgan_conv2d_wgrad16(C.byref(d), dt, L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(scr), st))
 e1.record(); torch.cuda.synchronize()

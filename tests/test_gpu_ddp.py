@@ -70,3 +70,27 @@ def test_trainer_data_parallel_world1():
     finally:
         os.environ.pop("ACLGAN_BENCH_FORCE_DIST", None); os.environ.pop("ACLGAN_DDP_OVERLAP", None)
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's complete N=2 control flow on the 1-GPU box: two ranks launched by torch.distributed.run share GPU 0 and talk
+    over gloo (RCCL refuses two ranks on one device): rank-0 broadcast, per-rank shards and z, the engine's bucket callback
+    starting one async all-reduce per gradient bucket from inside the backward on BOTH ranks, barrier / max-over-ranks timing,
+    one JSON line from rank 0 -- and after the steps the two replicas still hold bit-identical parameters."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.update(ACLGAN_DIST_BACKEND="gloo", ACLGAN_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ACLGAN_BENCH_FORCE_DIST", "ACLGAN_DDP_OVERLAP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["rccl_world_size"] == 2
+    assert out["config"]["grad_allreduce"].startswith("overlapped") and out["config"]["dist_backend"] == "gloo"
+    assert out["config"]["replicas_identical"] is True and out["config"]["losses_finite"] is True
+    assert r.stdout.strip().splitlines()[-1].startswith("{")      # the JSON line is the last line of stdout
