@@ -58,6 +58,12 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
 int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr);
 size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g);
 
+// Winograd F(4x4,3x3) path of the 3x3 stride-1 reflect-pad-1 layers (conv_wino.hip); EUNSUPPORTED when not eligible / no scratch
+bool conv_wino_ok(const ConvGeom& g);
+size_t conv_wino_scratch_bytes(const ConvGeom& g);
+int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st);
+int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);
+
 // 16-bit MFMA kernels (conv_fast16.hip): operands rounded to bf16 / fp16, fp32 accumulation and outputs.
 // which: 0 forward, 1 dgrad, 2 wgrad.  EUNSUPPORTED when the shape is not eligible.
 bool conv16_eligible(const ConvGeom& g, int which);

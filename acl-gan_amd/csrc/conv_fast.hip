@@ -96,9 +96,11 @@ __device__ __forceinline__ void mfma_step(const float (&fa)[TM][8], const float 
 // ------------------------------------------------------------------------------------------
 
 template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_fwd_fast_kernel(FwdFP p) {
+__global__ void __launch_bounds__(WM * WN * 64) conv_fwd_fast_kernel(FwdFP pk) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int RP = NT / 4;                 // rows covered per pass (4 float4 chunks per 16-float row)
+    FwdFP p = pk;
+    if (pk.fsl) { const long long f = blockIdx.y; p.x += f * pk.fs_x; p.w += f * pk.fs_w; p.y += f * pk.fs_y; }   // batched GEMM slice
     constexpr int A_IT = BM / RP, B_IT = (BN + RP - 1) / RP;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
     __shared__ int ro[BM];                     // output pixel index of each tile row (-1: not stored)
@@ -515,7 +517,8 @@ int dgrad_fast_all(const ConvGeom& g, DgFP p, float* dxp, float* dx, int accumul
         int rc = launch_dgrad_fast_merged<WM, WN, TM, TN>(g, p, st);
         if (rc != ACLGAN_EUNSUPPORTED) return rc;
         p.mode = 1;
-        rc = launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
+        rc = (dxp && conv_wino_ok(g)) ? conv_dgrad_wino_interior(g, p.dy, p.w, dx, accumulate, dxp, st)   // interior: Winograd (zero pad, flipped w^T)
+                                      : launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
         if (rc) return rc;
         if (g.p > 0) { p.mode = 2; rc = launch_dgrad_fast<WM, WN, TM, TN>(g, p, st); }
         return rc;
@@ -907,6 +910,7 @@ int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bi
     hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
     ACL_CHECK_LAUNCH("up5_merge_kernel");
     FwdFP p;
+    p.fsl = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
     // (1) the four phases: valid 3x3 conv on the low-res input, scattered into the 2H x 2W output
     p.x = x; p.w = wp; p.bias = bias; p.y = y;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.Co = g.Co; p.k = 3; p.s = 1; p.p = 0;
@@ -999,6 +1003,7 @@ size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g) {
 // forward scratch: merged phase weights + ring split-K partials (sub-pixel layers), or the split-K partials of a small-grid layer
 size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled()) return 0;
+    if (conv_wino_ok(g)) return conv_wino_scratch_bytes(g);
     if (up5_eligible(g)) return conv_up5_scratch_bytes(g) + fwd_partial_bytes(g, 2, BK);
     return fwd_partial_bytes(g, 0, BK);
 }
@@ -1028,10 +1033,37 @@ int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw
     return up5_wgrad_t<1, 4, 1, 2>(g, x, dy, dw, db, (float*)scratch, st);
 }
 
+// C_f[T][N] = A_f[T][K] x B_f[N][K]^T for f = 0 .. nslices-1 (fp32, exact MFMA): the tuned forward kernel run as a 1x1 "conv" over a
+// T x 1 "image", slice f on blockIdx.y.  K % 16 == 0.  Used by the Winograd path (conv_wino.hip).
+int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, hipStream_t st) {
+    if (K % 16 != 0 || T <= 0 || N <= 0) { set_error("gemm_slices_f32: bad shape"); return ACLGAN_EINVAL; }
+    FwdFP p;
+    p.part = nullptr; p.rows = 0; p.w16 = nullptr; p.x16 = nullptr;
+    p.x = A; p.w = Bm; p.bias = nullptr; p.y = Cm;
+    p.Hi = T; p.Wi = 1; p.Ci = K; p.Ho = T; p.Wo = 1; p.Co = N; p.k = 1; p.s = 1; p.p = 0;
+    p.up = 0; p.Hu = T; p.Wu = 1; p.M = T; p.K = K; p.act = ACLGAN_ACT_NONE; p.tiles_n = 0; p.nwg = 0; p.nkz = K / BK;
+    p.B = 1; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
+    p.fsl = nslices; p.fs_x = (long long)T * K; p.fs_w = (long long)N * K; p.fs_y = (long long)T * N;
+    if (N > 64) {
+        p.tiles_n = cdiv(N, 128); p.nwg = cdiv(T, 128) * p.tiles_n;
+        hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+    } else if (N > 32) {
+        p.tiles_n = cdiv(N, 64); p.nwg = cdiv(T, 256) * p.tiles_n;
+        hipLaunchKernelGGL((conv_fwd_fast_kernel<4, 1, 2, 2>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+    } else {
+        p.tiles_n = cdiv(N, 32); p.nwg = cdiv(T, 256) * p.tiles_n;
+        hipLaunchKernelGGL((conv_fwd_fast_kernel<4, 1, 2, 1>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+    }
+    ACL_CHECK_LAUNCH("conv_fwd_fast_kernel(gemm slices)");
+    return ACLGAN_OK;
+}
+
 // returns ACLGAN_EUNSUPPORTED when the shape is not eligible (caller falls back to the general kernel)
 int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch) {
     if (!fast_enabled() || g.Ci % 16 != 0) return ACLGAN_EUNSUPPORTED;
+    if (scratch && conv_wino_ok(g)) return conv_fwd_wino(g, x, w, bias, y, scratch, st);   // 3x3 ResBlock convs: Winograd F(4x4,3x3)
     FwdFP p;
+    p.fsl = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
     p.part = (float*)scratch; p.rows = 0;
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;

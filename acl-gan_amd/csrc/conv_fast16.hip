@@ -735,6 +735,7 @@ size_t up5_w16_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * 
 FwdFP fwd_params(const ConvGeom& g, const float* x, const u16* w16, const float* bias, float* y, const u16* x16 = nullptr) {
     FwdFP p;
     p.part = nullptr; p.rows = 0; p.w = nullptr; p.w16 = w16; p.x16 = x16;
+    p.fsl = 0; p.fs_x = p.fs_w = p.fs_y = 0;
     p.x = x; p.bias = bias; p.y = y;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.M = g.M; p.K = g.K; p.act = g.act; p.tiles_n = 0; p.nwg = 0; p.nkz = 0;

@@ -60,6 +60,9 @@ struct FwdFP {
     float* part; int rows;
     const unsigned short* w16;   // 16-bit kernels: OHWI weights (or merged phase weights) as bf16 / fp16 bit patterns
     const unsigned short* x16;   // 16-bit kernels, optional: the input already rounded to the 16-bit type by its producer (same NHWC layout)
+    // batched plain GEMMs (the 36 frequency planes of the Winograd path): blockIdx.y = slice f, operands / result of slice f start
+    // fs_* floats after those of slice 0.  0 = off.
+    int fsl; long long fs_x, fs_w, fs_y;
 };
 
 __device__ __forceinline__ bool fwd_row(const FwdFP& p, int m, int& b, int& oy, int& ox) {

@@ -1,0 +1,221 @@
+// conv_wino.hip -- Winograd F(4x4, 3x3) for the 3x3 stride-1 reflect-pad-1 convolutions (the eight ResBlock convs of every
+// content encoder and decoder pass, networks.py:297-310: 82 % of the step's MACs).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 4x4 output tile, per (cin, cout) pair; (.) = elementwise
+//
+// 36 multiplies per 16 outputs instead of 144: 4x fewer MACs on the fp32 matrix cores, at the price of two memory-bound
+// transform passes.  The elementwise product summed over cin is, per frequency f = 0..35, a plain GEMM
+//   M_f[T][Cout] = V_f[T][Cin] x U_f[Cout][Cin]^T          T = B * (H/4) * (W/4) tiles
+// and runs on the tuned forward kernel itself (gemm_slices_f32: conv_fwd_fast_kernel as a 1x1 "conv", slice f on blockIdx.y).
+//
+// Precision: fp32 everywhere; the transforms (coefficients up to 8) cost ~1.5 decimal digits -- measured 1.3e-5 max-abs
+// relative error per convolution against 2.7e-7 for the direct kernel (north-star tolerance of the forward: 1e-3).  The
+// reference itself runs these layers through cuDNN with cudnn.benchmark = True (train.py:29), whose fp32 algorithm choice
+// for 3x3 stride-1 convolutions is the same family.  ACLGAN_NOWINO=1 selects the direct kernels everywhere.
+//
+// The reflection padding of the forward lives in the input-transform gather; the backward w.r.t. the input uses the same
+// pipeline on dy with ZERO padding and the flipped / transposed filter for the interior of dx (the halo ring of the padded grid
+// keeps its small direct launch, conv_fast.hip mode 2).  The weight gradient stays on the direct kernel.
+#include "common.h"
+#include <cstdlib>
+#include <algorithm>
+
+namespace aclgan {
+
+int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, hipStream_t st);   // conv_fast.hip
+
+namespace {
+
+__device__ __forceinline__ int reflw(int v, int n) {
+    v = v < 0 ? -v : v;
+    return v >= n ? 2 * (n - 1) - v : v;
+}
+__device__ __forceinline__ float actw(float v, int act) {
+    if (act == ACLGAN_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACLGAN_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    if (act == ACLGAN_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// B^T d (input transform along one axis), G g (filter), A^T m (output)
+__device__ __forceinline__ void bt6(const float (&d)[6], float (&t)[6]) {
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void g6(const float (&g)[3], float (&u)[6]) {
+    u[0] = 0.25f * g[0];
+    u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
+    u[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
+    u[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    u[5] = g[2];
+}
+__device__ __forceinline__ void at4(const float (&m)[6], float (&y)[4]) {
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
+    y[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
+    y[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
+}
+
+// U[f][row][k]: forward: row = cout, k = cin from w[cout][ky][kx][cin];
+// dgrad (flip = 1): row = cin, k = cout from the flipped filter w[cout][2-ky][2-kx][cin]
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int flip) {
+    // one thread = one (row, k) pair of the OUTPUT layout, k fastest: forward (row = cout, k = cin) reads w coalesced along cin;
+    // dgrad (row = cin, k = cout, flipped taps) reads w with stride 9*Cin -- 9 strided loads per thread against 36 coalesced stores
+    const int R = flip ? Ci : Co, K = flip ? Co : Ci;
+    const int64_t n = (int64_t)R * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int kk = (int)(i % K), row = (int)(i / K);
+        const int co = flip ? kk : row, ci = flip ? row : kk;
+        float t[6][3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {            // G g: columns
+            float c[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                c[ky] = w[((size_t)(co * 3 + sy) * 3 + sx) * Ci + ci];
+            }
+            float o[6];
+            g6(c, o);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) t[a][kx] = o[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {               // (G g) G^T: rows
+            float o[6];
+            g6(t[a], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) U[((size_t)(a * 6 + j) * R + row) * K + kk] = o[j];
+        }
+    }
+}
+
+// V[f][t][c] = (B^T d B)[f] of the 6x6 input patch of tile t = (b, ty, tx): rows 4ty-1 .. 4ty+4 (reflect or zero padding)
+__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int zero_pad) {
+    const int TY = H >> 2, TX = W >> 2;
+    const int64_t T = (int64_t)B * TY * TX, n = T * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
+        float tmp[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {              // columns of the patch: B^T d
+            float d[6];
+            const int ixr = 4 * tx - 1 + j;
+            const bool xin = (unsigned)ixr < (unsigned)W;
+            const int ix = reflw(ixr, W);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int iyr = 4 * ty - 1 + r;
+                const bool in = xin && (unsigned)iyr < (unsigned)H;
+                const int iy = reflw(iyr, H);
+                const float v = x[((size_t)(b * H + iy) * W + ix) * C + c];
+                d[r] = (zero_pad && !in) ? 0.f : v;
+            }
+            float o[6];
+            bt6(d, o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tmp[r][j] = o[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {              // rows: (B^T d) B
+            float o[6];
+            bt6(tmp[r], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) V[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
+        }
+    }
+}
+
+// y[b][4ty+i][4tx+j][c] (+)= act((A^T M A)[i][j] + bias[c])
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                          int W, int C, int act, int accumulate) {
+    const int TY = H >> 2, TX = W >> 2;
+    const int64_t T = (int64_t)B * TY * TX, n = T * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
+        float tmp[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {              // columns: A^T M
+            float m[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) m[r] = M[((size_t)(r * 6 + j) * T + t) * C + c];
+            float o[4];
+            at4(m, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tmp[r][j] = o[r];
+        }
+        const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {              // rows: (A^T M) A
+            float o[4];
+            at4(tmp[r], o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* dst = y + ((size_t)(b * H + 4 * ty + r) * W + 4 * tx + j) * C + c;
+                const float v = actw(o[j] + bv, act);
+                *dst = accumulate ? *dst + v : v;
+            }
+        }
+    }
+}
+
+bool wino_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_NOWINO"); v = (e && atoi(e)) ? 0 : 1; }
+    return v == 1;
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// the pipeline: filter transform -> input transform -> 36 GEMMs -> output transform.  `in` has Cin_ channels, `out` Cout_.
+int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* w, int w_co, int w_ci, int flip, const float* bias, float* out,
+             int act, int accumulate, int zero_pad, void* scratch, hipStream_t st) {
+    const int64_t T = (int64_t)B * (H / 4) * (W / 4);
+    float* U = (float*)scratch;
+    float* V = (float*)((char*)scratch + align256((size_t)36 * Cout_ * Cin_ * sizeof(float)));
+    float* M = (float*)((char*)V + align256((size_t)36 * T * Cin_ * sizeof(float)));
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)w_co * w_ci, 256), 4096)), dim3(256), 0, st, w, U, w_co, w_ci, flip);
+    ACL_CHECK_LAUNCH("wino_filter_kernel");
+    hipLaunchKernelGGL(wino_input_kernel, dim3((int)std::min<int64_t>(cdiv64(T * Cin_, 256), 16384)), dim3(256), 0, st, in, V, B, H, W, Cin_, zero_pad);
+    ACL_CHECK_LAUNCH("wino_input_kernel");
+    const int rc = gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_output_kernel, dim3((int)std::min<int64_t>(cdiv64(T * Cout_, 256), 16384)), dim3(256), 0, st, M, bias, out, B, H, W, Cout_, act,
+                       accumulate);
+    ACL_CHECK_LAUNCH("wino_output_kernel");
+    return ACLGAN_OK;
+}
+
+}  // namespace
+
+// 3x3, stride 1, reflect pad 1, no upsample, 4x4-tileable output, channel counts the GEMM kernel takes, and enough channels to pay
+bool conv_wino_ok(const ConvGeom& g) {
+    return wino_enabled() && g.k == 3 && g.s == 1 && g.p == 1 && g.up == 0 && g.Ho % 4 == 0 && g.Wo % 4 == 0 && g.Ci % 16 == 0 && g.Co % 16 == 0 &&
+           (int64_t)g.Ci * g.Co >= 64 * 64;
+}
+size_t conv_wino_scratch_bytes(const ConvGeom& g) {
+    if (!conv_wino_ok(g)) return 0;
+    const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
+    const int cmax = std::max(g.Ci, g.Co);      // forward: V has Cin, M has Cout channels; dgrad the other way round
+    return align256((size_t)36 * g.Co * g.Ci * sizeof(float)) + 2 * align256((size_t)36 * T * cmax * sizeof(float)) + 256;
+}
+int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st) {
+    if (!conv_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
+    return wino_run(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, w, g.Co, g.Ci, 0, bias, y, g.act, 0, 0, scratch, st);
+}
+// the INTERIOR of the padded-grid gradient (= dx without the mirrored halo contributions): dx (+)= dy (*) flipped w^T, zero padding
+int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st) {
+    if (!conv_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
+    return wino_run(g.B, g.Hi, g.Wi, g.Co, g.Ci, dy, w, g.Co, g.Ci, 1, nullptr, dx, ACLGAN_ACT_NONE, accumulate, 1, scratch, st);
+}
+
+}  // namespace aclgan
