@@ -63,6 +63,8 @@ bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_scratch_bytes(const ConvGeom& g);
 int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st);
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);
+size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g);
+int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
 
 // 16-bit MFMA kernels (conv_fast16.hip): operands rounded to bf16 / fp16, fp32 accumulation and outputs.
 // which: 0 forward, 1 dgrad, 2 wgrad.  EUNSUPPORTED when the shape is not eligible.

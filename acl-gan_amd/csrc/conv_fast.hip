@@ -18,6 +18,7 @@
 //     current tile, so each wave's own instruction stream overlaps index/memory work with its
 //     MFMAs instead of relying on a second wave being in the complementary phase.
 #include "conv_fast_common.h"
+#include <cstring>
 
 namespace aclgan {
 namespace {
@@ -95,8 +96,10 @@ __device__ __forceinline__ void mfma_step(const float (&fa)[TM][8], const float 
 // forward (Cin % 16 == 0)
 // ------------------------------------------------------------------------------------------
 
-template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_fwd_fast_kernel(FwdFP pk) {
+// OCC: minimum workgroups per CU the register allocator must allow (1 = no constraint: the direct convolutions; 3 for the
+// batched GEMMs of the Winograd path, whose 1152-workgroup grids leave a half-empty third round at 2 workgroups per CU)
+template <int WM, int WN, int TM, int TN, int OCC = 1>
+__global__ void __launch_bounds__(WM * WN * 64, OCC) conv_fwd_fast_kernel(FwdFP pk) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int RP = NT / 4;                 // rows covered per pass (4 float4 chunks per 16-float row)
     FwdFP p = pk;
@@ -699,8 +702,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_fast_kernel(WgFP p) {
 constexpr int WGKC_TARGET = 768;     // workgroups in flight the split plan aims for (3 per CU fit: LDS)
 
 template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_kc_kernel(WgFP p, WgPartX xp) {
+__global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_kc_kernel(WgFP pk, WgPartX xp) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+    WgFP p = pk;
+    if (pk.fsl) { const long long f = blockIdx.y; p.x += f * pk.fs_x; p.dy += f * pk.fs_dy; }   // batched GEMM slice
     static_assert(BM % 64 == 0 && BN % 64 == 0 && BM + BN <= NT, "one staging unit (4 channels x 4 pixels) per thread, wave-uniform roles");
     constexpr int CH = 1024;                   // pixels per sub-chunk
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
@@ -714,7 +719,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_kc_kernel(WgFP p, WgP
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int pbeg = blockIdx.z * p.chunk;
     const int pend = min(p.P, pbeg + p.chunk);
-    const int phase = p.phases ? (int)blockIdx.y : 0;
+    const int phase = (p.phases || p.fsl) ? (int)blockIdx.y : 0;
     float* dwbase = p.dw + (size_t)phase * p.Co * p.Kn;
     const int py = phase >> 1, px = phase & 1;
     const int st_tap = n0 / p.Ci, st_ky = st_tap / p.k, st_kx = st_tap - st_ky * p.k;   // the whole N tile lies inside ONE filter tap
@@ -843,7 +848,7 @@ bool wgrad_kc_ok(const ConvGeom& g) {
 template <int WM, int WN, int TM, int TN>
 int launch_wgrad_kc(const ConvGeom& g, WgFP p, void* part, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const int ny = p.phases ? 4 : 1;
+    const int ny = p.fsl ? p.fsl : (p.phases ? 4 : 1);
     const WgPlan q = wgrad_plan(g.Co, p.Ci, p.Kn, p.P, ny, BK, WGKC_TARGET);
     if (q.BM != BM || q.BN != BN) { set_error("wgrad_kc: tile plan mismatch"); return ACLGAN_EINVAL; }
     p.tiles_n = q.tiles_n; p.nwg = q.nwg; p.chunk = q.chunk;
@@ -937,6 +942,7 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
     const bool kc = wgrad_kc_ok(g);
     void* part = (char*)dwp + up5_dwp_bytes(g);      // partial tiles of the ordered-slice kernels follow the phase gradients
     WgFP p;
+    p.fsl = 0; p.fs_x = p.fs_dy = 0;
     p.x = x; p.dy = dy; p.dw = dwp; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.Co = g.Co; p.k = 3; p.s = 1; p.p = 0;
     p.up = 0; p.Hu = g.Hi; p.Wu = g.Wi; p.P = g.B * p.Ho * p.Wo; p.Kn = 9 * g.Ci; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
@@ -997,6 +1003,7 @@ size_t conv_up5_scratch_bytes(const ConvGeom& g) {
 // ordered-slice kernel (0 when neither applies)
 size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled()) return 0;
+    if (wgrad_kc_ok(g) && conv_wino_ok(g)) return conv_wgrad_wino_scratch_bytes(g);
     if (wgrad_kc_ok(g)) return wgrad_part_scratch(g, BK, WGKC_TARGET);
     return conv_up5_scratch_bytes(g);
 }
@@ -1046,7 +1053,10 @@ int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, in
     p.fsl = nslices; p.fs_x = (long long)T * K; p.fs_w = (long long)N * K; p.fs_y = (long long)T * N;
     if (N > 64) {
         p.tiles_n = cdiv(N, 128); p.nwg = cdiv(T, 128) * p.tiles_n;
-        hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+        static int occ3 = -1;
+        if (occ3 < 0) { const char* e = getenv("ACLGAN_GEMM_OCC2"); occ3 = (e && atoi(e)) ? 0 : 1; }
+        if (occ3) hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2, 3>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
     } else if (N > 32) {
         p.tiles_n = cdiv(N, 64); p.nwg = cdiv(T, 256) * p.tiles_n;
         hipLaunchKernelGGL((conv_fwd_fast_kernel<4, 1, 2, 2>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
@@ -1095,13 +1105,34 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
     return dgrad_fast_all<4, 1, 2, 1>(g, p, dxp, dx, accumulate, direct, st);
 }
 
+// C_f[M][N] += sum_t A_f[t][M] * B_f[t][N] for f = 0 .. nslices-1 (fp32): the ordered-slice weight-gradient kernel run as a 1x1 "conv"
+// over a T x 1 "image".  M, N multiples of 64.  part: gemm_at_b_slices_scratch(...) bytes.  Used by the Winograd path.
+size_t gemm_at_b_slices_scratch(int T, int M, int N, int nslices) {
+    return wgrad_partial_bytes(wgrad_plan(M, N, N, T, nslices, BK, WGKC_TARGET), M, nslices) + 256;
+}
+int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int M, int N, int nslices, void* part, hipStream_t st) {
+    if (M % 64 != 0 || N % 64 != 0 || T <= 0) { set_error("gemm_at_b_slices_f32: bad shape"); return ACLGAN_EINVAL; }
+    WgFP p;
+    p.x = Bm; p.dy = A; p.dw = Cm; p.db = nullptr;
+    p.Hi = T; p.Wi = 1; p.Ci = N; p.Ho = T; p.Wo = 1; p.Co = M; p.k = 1; p.s = 1; p.p = 0;
+    p.up = 0; p.Hu = T; p.Wu = 1; p.P = T; p.Kn = N; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
+    p.B = 1; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
+    p.fsl = nslices; p.fs_x = (long long)T * N; p.fs_dy = (long long)T * M;
+    ConvGeom g;
+    memset(&g, 0, sizeof g);
+    g.Co = M; g.Ci = N;
+    return launch_wgrad_kc_any(g, p, part, st);
+}
+
 int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
     if (!fast_enabled() || g.Co % 4 != 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     WgFP p;
+    p.fsl = 0; p.fs_x = p.fs_dy = 0;
     p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.P = g.M; p.Kn = g.K; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
     p.B = g.B; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
+    if (scratch && conv_wino_ok(g) && wgrad_kc_ok(g)) return conv_wgrad_wino(g, x, dy, dw, db, scratch, st);   // 3x3 ResBlock convs: Winograd
     // with a scratch buffer (always, inside the engine): k-contiguous tiles + ordered slices, reproducible bit for bit;
     // the scratch-less operator call keeps the atomics kernel
     if (wgrad_kc_ok(g) && (scratch || wgrad_part_scratch(g, BK, WGKC_TARGET) == 0)) return launch_wgrad_kc_any(g, p, scratch, st);

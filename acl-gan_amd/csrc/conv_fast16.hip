@@ -863,6 +863,7 @@ int dgrad16_t(const ConvGeom& g, const float* dy, const float* w, const u16* w16
 
 WgFP wg_params(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db) {
     WgFP p;
+    p.fsl = 0; p.fs_x = p.fs_dy = 0;
     p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.P = g.M; p.Kn = g.K; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;

@@ -239,6 +239,9 @@ struct WgFP {
     // of that width are summed (exact gather); phases = 1: blockIdx.y is the output phase, dy is read at
     // [2(oy+1)+py][2(ox+1)+px] of an Hf x Wf map and the result goes to dw + phase*Co*Kn
     int B, ring, phases, Hf, Wf;
+    // batched plain "A^T B" GEMMs (the 36 frequency planes of the Winograd weight gradient): blockIdx.y = slice f; x / dy of slice
+    // f start fs_x / fs_dy floats after those of slice 0; the result goes to dw + f*Co*Kn (like a phase).  0 = off.
+    int fsl; long long fs_x, fs_dy;
 };
 
 __device__ __forceinline__ void wg_coord(const WgFP& p, int pix, int& b, int& oy, int& ox) {

@@ -23,6 +23,8 @@
 namespace aclgan {
 
 int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, hipStream_t st);   // conv_fast.hip
+size_t gemm_at_b_slices_scratch(int T, int M, int N, int nslices);
+int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int M, int N, int nslices, void* part, hipStream_t st);
 
 namespace {
 
@@ -168,6 +170,104 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
     }
 }
 
+// ---- weight gradient in the Winograd domain:  dU_f[co][ci] = sum_t dM_f[t][co] V_f[t][ci],  dM = A dY A^T,  dg = G^T dU G ----
+__device__ __forceinline__ void a6(const float (&y)[4], float (&m)[6]) {     // A y  (A = transpose of A^T, 6 x 4)
+    m[0] = y[0];
+    m[1] = y[0] + y[1] + y[2] + y[3];
+    m[2] = y[0] - y[1] + y[2] - y[3];
+    m[3] = y[0] + 2.f * y[1] + 4.f * y[2] + 8.f * y[3];
+    m[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+    m[5] = y[3];
+}
+__device__ __forceinline__ void gt3(const float (&u)[6], float (&g)[3]) {    // G^T u
+    g[0] = 0.25f * u[0] - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
+    g[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+    g[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
+}
+
+// dM[f][t][c] = (A dY A^T)[f] of the 4x4 output-gradient tile t; bpart[j][c] (optional) = this thread's column sum of dy (bias
+// gradient, reduced in order by wino_bias_finish_kernel).  Launch with gridDim.x * 256 a multiple of C: a thread keeps ONE channel.
+__global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ bpart, int B, int H, int W,
+                                                           int C) {
+    const int TY = H >> 2, TX = W >> 2;
+    const int64_t T = (int64_t)B * TY * TX;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    const int c = (int)(gid % C);
+    float bs = 0.f;
+    for (int64_t t = gid / C; t < T; t += nth / C) {
+        const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
+        float tmp[6][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {              // columns: A dY
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = dy[((size_t)(b * H + 4 * ty + r) * W + 4 * tx + j) * C + c]; bs += v[r]; }
+            float o[6];
+            a6(v, o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tmp[r][j] = o[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {              // rows: (A dY) A^T
+            float o[6];
+            a6(tmp[r], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dM[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
+        }
+    }
+    if (bpart) bpart[gid] = bs;                    // [gid / C][c]
+}
+// db[c] += sum over the partial rows, in a fixed order: 16 channels x 16 row groups per workgroup, groups combined through LDS
+__global__ void __launch_bounds__(256) wino_bias_finish_kernel(const float* __restrict__ bpart, int rows, int C, float* __restrict__ db) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int per = (rows + 15) >> 4;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        const int jb = rg * per, je = min(rows, jb + per);
+        int j = jb;
+        for (; j + 3 < je; j += 4) {
+            s0 += bpart[(size_t)j * C + c]; s1 += bpart[(size_t)(j + 1) * C + c];
+            s2 += bpart[(size_t)(j + 2) * C + c]; s3 += bpart[(size_t)(j + 3) * C + c];
+        }
+        for (; j < je; ++j) s0 += bpart[(size_t)j * C + c];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+        db[c] += t;
+    }
+}
+// dw[co][ky][kx][ci] += (G^T dU G)[ky][kx] of dU[f][co][ci]
+__global__ void __launch_bounds__(256) wino_filtergrad_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci) {
+    const int64_t n = (int64_t)Co * Ci;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % Ci), co = (int)(i / Ci);
+        float t[3][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {              // columns: G^T dU
+            float u[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[r] = dU[((size_t)(r * 6 + j) * Co + co) * Ci + ci];
+            float o[3];
+            gt3(u, o);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) t[r][j] = o[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {              // rows: (G^T dU) G
+            float o[3];
+            gt3(t[r], o);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dw[((size_t)(co * 3 + r) * 3 + j) * Ci + ci] += o[j];
+        }
+    }
+}
+
 bool wino_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("ACLGAN_NOWINO"); v = (e && atoi(e)) ? 0 : 1; }
@@ -216,6 +316,43 @@ int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st) {
     if (!conv_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     return wino_run(g.B, g.Hi, g.Wi, g.Co, g.Ci, dy, w, g.Co, g.Ci, 1, nullptr, dx, ACLGAN_ACT_NONE, accumulate, 1, scratch, st);
+}
+
+// weight (and bias) gradient.  scratch: V [36][T][Cin] | dM [36][T][Cout] | dU [36][Cout][Cin] | bias partials | GEMM partial tiles
+namespace {
+const int WINO_BIAS_BLOCKS = 1024;       // x 256 threads: a multiple of every channel count in {64, 128, 256, 512}
+}
+size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g) {
+    if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
+    const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
+    return align256((size_t)36 * T * g.Ci * 4) + align256((size_t)36 * T * g.Co * 4) + align256((size_t)36 * g.Co * g.Ci * 4) +
+           align256((size_t)WINO_BIAS_BLOCKS * 256 * 4) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
+}
+int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
+    if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
+    if ((WINO_BIAS_BLOCKS * 256) % g.Co != 0) return ACLGAN_EUNSUPPORTED;
+    const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
+    char* s = (char*)scratch;
+    float* V = (float*)s;  s += align256((size_t)36 * T * g.Ci * 4);
+    float* dM = (float*)s; s += align256((size_t)36 * T * g.Co * 4);
+    float* dU = (float*)s; s += align256((size_t)36 * g.Co * g.Ci * 4);
+    float* bpart = (float*)s; s += align256((size_t)WINO_BIAS_BLOCKS * 256 * 4);
+    void* part = s;
+    hipLaunchKernelGGL(wino_input_kernel, dim3((int)std::min<int64_t>(cdiv64(T * g.Ci, 256), 16384)), dim3(256), 0, st, x, V, g.B, g.Hi, g.Wi, g.Ci, 0);
+    ACL_CHECK_LAUNCH("wino_input_kernel");
+    hipLaunchKernelGGL(wino_outgrad_kernel, dim3(WINO_BIAS_BLOCKS), dim3(256), 0, st, dy, dM, db ? bpart : (float*)nullptr, g.B, g.Ho, g.Wo, g.Co);
+    ACL_CHECK_LAUNCH("wino_outgrad_kernel");
+    if (db) {
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, WINO_BIAS_BLOCKS * 256 / g.Co, g.Co, db);
+        ACL_CHECK_LAUNCH("wino_bias_finish_kernel");
+    }
+    hipError_t e = hipMemsetAsync(dU, 0, (size_t)36 * g.Co * g.Ci * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail(e, "memset dU");
+    const int rc = gemm_at_b_slices_f32(dM, V, dU, (int)T, g.Co, g.Ci, 36, part, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_filtergrad_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)g.Co * g.Ci, 256), 4096)), dim3(256), 0, st, dU, dw, g.Co, g.Ci);
+    ACL_CHECK_LAUNCH("wino_filtergrad_kernel");
+    return ACLGAN_OK;
 }
 
 }  // namespace aclgan

@@ -22,8 +22,10 @@ Extra objects in the JSON line:
   roofline     MFMA-bound.  achieved = contract FLOPs (2.623 TFLOP per image at 256^2: NECESSARY conv+linear work of
                one dis+gen step) x images per step / event-timed step, against the matrix peak of the
                compute dtype (157.3 TFLOP/s fp32, 2500 bf16/fp16).  `executed_*`: the FLOPs the kernels really issue
-               (the sub-pixel path runs the two upsample+5x5 layers with 9 instead of 25 taps away from the border),
-               i.e. the hardware utilisation figure.  "kernel": the dominant kernel alone, timed with HIP events.
+               (sub-pixel path: the two upsample+5x5 layers with 9 instead of 25 taps away from the border; fp32: the 3x3
+               ResBlock convolutions through Winograd F(4x4,3x3) with 1/4 of the MACs), i.e. the hardware utilisation
+               figure -- the contract `frac` can approach or exceed 1 because of those algorithmic savings.
+               "kernel": the dominant kernel alone, timed with HIP events.
   cpu_baseline the CPU oracle (a port of the reference step, oracle/aclgan_oracle.py) on the host cores, rank 0 at
                N=1 only: 1 warm-up + 3 timed steps at 256x256 B=1, median and spread.
 """
@@ -52,12 +54,18 @@ def male2female_config():
         return yaml.safe_load(f)
 
 
-def flops_per_image(S):
-    """(contract, executed) TFLOP per image of one dis+gen step at SxS.  Executed: inside the border ring the
-    sub-pixel decomposition issues 9/25 of the upsample+5x5 MACs."""
+RESBLOCK_GMAC_256 = 637.8     # of which the 3x3 ResBlock convs: 120 forward + 72 dgrad + 72 wgrad launches x 2.4159 GMAC
+
+
+def flops_per_image(S, dtype="fp32"):
+    """(contract, executed) TFLOP per image of one dis+gen step at SxS.  Executed = what the kernels really issue: inside the
+    border ring the sub-pixel decomposition runs 9/25 of the upsample+5x5 MACs, and (fp32 only) the Winograd F(4x4,3x3) path runs
+    the 3x3 ResBlock convolutions -- forward, dgrad interior, wgrad -- with 36/144 of theirs."""
     scale = (S / 256.0) ** 2
     interior = 0.5 * (((S // 2 - 4) / (S // 2)) ** 2 + ((S - 4) / S) ** 2)
     executed_gmac = 1311.6 - UPCONV_GMAC_256 * (16.0 / 25.0) * interior
+    if dtype == "fp32" and S % 16 == 0 and os.environ.get("ACLGAN_NOWINO", "0") in ("", "0"):
+        executed_gmac -= RESBLOCK_GMAC_256 * 0.75
     return TFLOP_PER_IMAGE_256 * scale, 2e-3 * executed_gmac * scale
 
 
@@ -111,6 +119,7 @@ def dominant_kernel_probe(L, dtype, reps=20):
     ~97% of the step's FLOPs.  Timed with HIP events on the launch stream."""
     import ctypes as C
     B, H, Cc = 8, 64, 256
+    flop_direct = 2.0 * (B * H * H) * Cc * (9 * Cc)
     x = torch.randn(B, H, H, Cc, device="cuda")
     w = torch.randn(Cc, 3, 3, Cc, device="cuda") * 0.02
     b = torch.zeros(Cc, device="cuda")
@@ -118,11 +127,15 @@ def dominant_kernel_probe(L, dtype, reps=20):
     d = L.ConvDesc(B, H, H, Cc, Cc, 3, 1, 1, 0, 0)
     st = L.stream_ptr()
     if dtype == "fp32":
-        call = lambda: L.check(L.lib.aclgan_conv2d_fwd(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), st))   # noqa: E731
-        name = "conv_fwd_fast_kernel<2,2,2,2> 8x64x64x256->256 3x3 (ResBlock conv, 135 launches per step)"
-        # HBM-side bytes per launch of THIS kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot
-        # run inside the timed process): 2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE
-        extra = {"traffic": 207.8e6 + 32.8e6, "algorithmic_bytes": 69.5e6, "traffic_source": "profiles/r01_hbm_traffic_conv_fwd.txt"}
+        nb = L.lib.aclgan_conv2d_fwd_scratch_bytes(C.byref(d))
+        scr = torch.empty(nb // 4 + 64, device="cuda")
+        # the ResBlock convolution as the step runs it (with scratch): Winograd F(4x4,3x3) = filter / input transform, 36 batched
+        # GEMMs on conv_fwd_fast_kernel<2,2,2,2,3>, output transform.  achieved = ALGORITHMIC (direct-convolution) FLOPs / time.
+        call = lambda: L.check(L.lib.aclgan_conv2d_fwd_ws(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(scr), st))   # noqa: E731
+        name = "ResBlock conv 8x64x64x256->256 3x3 forward (Winograd F(4x4,3x3): 4 launches, GEMMs on conv_fwd_fast_kernel<2,2,2,2,3>)"
+        # algorithmic bytes = input + weights + output; HBM-side traffic of the Winograd pipeline adds the V / M planes (2 x 75 MB
+        # written and read once each, mostly served by the 256 MB Infinity Cache) -- not re-measured with PMC this round
+        extra = {"traffic": None, "algorithmic_bytes": 69.5e6, "executed_flop_per_launch": flop_direct * 0.25 if os.environ.get("ACLGAN_NOWINO", "0") in ("", "0") else flop_direct}
     else:
         code = L.DTYPE[dtype]
         w16 = torch.empty(w.numel(), dtype=torch.int16, device="cuda")
@@ -275,7 +288,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
-        tflop_img, tflop_exec = flops_per_image(S)
+        tflop_img, tflop_exec = flops_per_image(S, args.dtype)
         step_s = ev_ms / args.steps / 1e3
         ach = tflop_img * B / step_s      # per GPU, from HIP events on the launch stream
         peak = PEAK[args.dtype]

@@ -9,7 +9,7 @@ oracle (oracle/aclgan_oracle.py, pinned to the reference by tests/golden) and ar
   * forward tensors (contents, styles, decoder outputs after the focus blend, the consistency pass,
     discriminator maps)                                       <= 1e-4 rel (north-star tolerance: 1e-3)
   * the 16 reported losses                                    <= 1e-4 rel ('size' losses 2e-2)
-  * one dis_update + one gen_update: every gradient tensor    <= 5e-3 relative L2 (smooth fixture:
+  * one dis_update + one gen_update: every gradient tensor    <= 1e-2 relative L2 (smooth fixture:
     focus_epsilon 0.5, see tests/golden/make_golden.py for why the default 0.01 is ill-conditioned)
 
 Oracle cost on the GPU box's host cores: ~4 s per 256^2 sample-step, so the whole file is a few minutes.
@@ -23,7 +23,8 @@ from oracle import aclgan_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-GTOL = 5e-3          # per-tensor relative L2 of the gradients; measured worst 2.8e-3 (profiles/r02_fullsize_parity_tests.log)
+GTOL = 1e-2          # per-tensor relative L2 of the gradients; measured worst 2.8e-3 with the direct 3x3 kernels (ACLGAN_NOWINO=1),
+                     # 4.7e-3 with the Winograd F(4x4,3x3) ResBlock path (its 1.3e-5 per-conv noise flips a few more ReLU masks)
 FTOL = 1e-4          # forward tensors, max-abs relative (north star: 1e-3; measured worst 1.6e-5)
 LTOL = 1e-4          # losses (measured worst 4e-7)
 
