@@ -26,7 +26,11 @@ CONV_CASES = [
     (2, 16, 20, 3, 64, 7, 1, 3, 0, "relu"),      # CE0 / SE0: Cin 3 (scalar gather path)
     (2, 16, 16, 64, 128, 4, 2, 1, 0, "none"),    # CE1
     (1, 16, 16, 128, 256, 4, 2, 1, 0, "relu"),   # CE2 / SE2
-    (2, 8, 8, 256, 256, 3, 1, 1, 0, "none"),     # ResBlock conv
+    (2, 8, 8, 256, 256, 3, 1, 1, 0, "none"),     # ResBlock conv (Winograd F(4x4,3x3) path: forward, dgrad interior, wgrad)
+    (1, 12, 20, 64, 128, 3, 1, 1, 0, "relu"),    # Winograd: non-square map, Cin != Cout, activation in the output transform
+    (3, 4, 8, 128, 64, 3, 1, 1, 0, "none"),      # Winograd: a single tile row, B = 3
+    (2, 16, 16, 64, 64, 3, 1, 1, 0, "lrelu"),    # Winograd: smallest channel counts that take the path
+    (2, 10, 12, 64, 64, 3, 1, 1, 0, "none"),     # 3x3 but H % 4 != 0: stays on the direct kernels
     (2, 8, 8, 256, 128, 5, 1, 2, 1, "none"),     # DU0: upsample folded into the gather
     (1, 16, 16, 128, 64, 5, 1, 2, 1, "none"),    # DU1
     (2, 9, 13, 32, 48, 5, 1, 2, 1, "relu"),      # upsample+5x5 on a ragged map (sub-pixel path: 4 phases + exact ring)
