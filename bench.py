@@ -135,7 +135,12 @@ def dominant_kernel_probe(L, dtype, reps=20):
         name = "ResBlock conv 8x64x64x256->256 3x3 forward (Winograd F(4x4,3x3): 4 launches, GEMMs on conv_fwd_fast_kernel<2,2,2,2,3>)"
         # algorithmic bytes = input + weights + output; HBM-side traffic of the Winograd pipeline adds the V / M planes (2 x 75 MB
         # written and read once each, mostly served by the 256 MB Infinity Cache) -- not re-measured with PMC this round
-        extra = {"traffic": None, "algorithmic_bytes": 69.5e6, "executed_flop_per_launch": flop_direct * 0.25 if os.environ.get("ACLGAN_NOWINO", "0") in ("", "0") else flop_direct}
+        wino = os.environ.get("ACLGAN_NOWINO", "0") in ("", "0")
+        # memory-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside the timed
+        # process): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, summed over the four launches of the pipeline
+        extra = {"traffic": 463.0e6 if wino else 240.6e6, "algorithmic_bytes": 69.5e6,
+                 "traffic_source": "profiles/r02_hbm_traffic_winograd.txt" if wino else "profiles/r01_hbm_traffic_conv_fwd.txt",
+                 "executed_flop_per_launch": flop_direct * 0.25 if wino else flop_direct}
     else:
         code = L.DTYPE[dtype]
         w16 = torch.empty(w.numel(), dtype=torch.int16, device="cuda")
@@ -156,6 +161,9 @@ def dominant_kernel_probe(L, dtype, reps=20):
     out = {"name": name, "ms": round(ms, 4), "flop_per_launch": flop, "achieved": round(flop / ms / 1e9, 2), "unit": "TFLOP/s",
            "frac": round(flop / ms / 1e9 / PEAK[dtype], 4)}
     out.update(extra)
+    if "executed_flop_per_launch" in out:   # the MACs really issued (Winograd: 1/4): the hardware-utilisation figure of this kernel
+        out["executed_achieved"] = round(out["executed_flop_per_launch"] / ms / 1e9, 2)
+        out["executed_frac"] = round(out["executed_flop_per_launch"] / ms / 1e9 / PEAK[dtype], 4)
     return out
 
 
