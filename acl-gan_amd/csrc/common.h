@@ -64,6 +64,15 @@ size_t conv_wino_scratch_bytes(const ConvGeom& g);
 int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st);
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);
 size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g);
+// the four VALID-3x3 phases of the sub-pixel upsample+5x5 path through Winograd (wp: merged fp32 phase filters [4][Co][3][3][Ci])
+bool conv_up5_wino_ok(const ConvGeom& g);
+size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g);
+size_t conv_up5_wino_dgrad_scratch_bytes(const ConvGeom& g);
+size_t conv_up5_wino_wgrad_scratch_bytes(const ConvGeom& g);
+int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st);
+int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st);
+int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st);
+size_t conv_up5_dgrad_scratch_bytes(const ConvGeom& g);
 int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
 
 // 16-bit MFMA kernels (conv_fast16.hip): operands rounded to bf16 / fp16, fp32 accumulation and outputs.

@@ -103,7 +103,10 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv_fwd_fast_kernel(FwdFP 
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int RP = NT / 4;                 // rows covered per pass (4 float4 chunks per 16-float row)
     FwdFP p = pk;
-    if (pk.fsl) { const long long f = blockIdx.y; p.x += f * pk.fs_x; p.w += f * pk.fs_w; p.y += f * pk.fs_y; }   // batched GEMM slice
+    if (pk.fsl) {   // batched GEMM slice
+        const long long f = blockIdx.y;
+        p.x += (pk.fsx_mod ? f % pk.fsx_mod : f) * pk.fs_x; p.w += f * pk.fs_w; p.y += f * pk.fs_y;
+    }
     constexpr int A_IT = BM / RP, B_IT = (BN + RP - 1) / RP;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
     __shared__ int ro[BM];                     // output pixel index of each tile row (-1: not stored)
@@ -705,7 +708,10 @@ template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_kc_kernel(WgFP pk, WgPartX xp) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     WgFP p = pk;
-    if (pk.fsl) { const long long f = blockIdx.y; p.x += f * pk.fs_x; p.dy += f * pk.fs_dy; }   // batched GEMM slice
+    if (pk.fsl) {   // batched GEMM slice
+        const long long f = blockIdx.y;
+        p.x += (pk.fsx_mod ? f % pk.fsx_mod : f) * pk.fs_x; p.dy += f * pk.fs_dy;
+    }
     static_assert(BM % 64 == 0 && BN % 64 == 0 && BM + BN <= NT, "one staging unit (4 channels x 4 pixels) per thread, wave-uniform roles");
     constexpr int CH = 1024;                   // pixels per sub-chunk
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
@@ -915,7 +921,7 @@ int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bi
     hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
     ACL_CHECK_LAUNCH("up5_merge_kernel");
     FwdFP p;
-    p.fsl = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
+    p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
     // (1) the four phases: valid 3x3 conv on the low-res input, scattered into the 2H x 2W output
     p.x = x; p.w = wp; p.bias = bias; p.y = y;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.Co = g.Co; p.k = 3; p.s = 1; p.p = 0;
@@ -923,13 +929,16 @@ int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bi
     p.B = g.B; p.ring = 0; p.phases = 1; p.Hf = g.Ho; p.Wf = g.Wo; p.part = nullptr; p.rows = 0;
     ConvGeom gp = g;
     gp.M = p.M; gp.K = p.K;
-    int rc = launch_fwd_fast<WM, WN, TM, TN>(gp, p, st);
+    // the phases are VALID 3x3 convolutions: Winograd F(4x4,3x3), all four in one batched GEMM (conv_wino.hip); scratch follows
+    // the merged filters and the ring partials
+    char* wino_scr = (char*)wp + up5_merged_bytes(g) + ((fwd_partial_bytes(g, 2, BK) + 255) & ~(size_t)255);
+    int rc = conv_up5_wino_ok(g) ? conv_up5_wino_fwd_phases(g, x, wp, bias, y, wino_scr, st) : launch_fwd_fast<WM, WN, TM, TN>(gp, p, st);
     if (rc) return rc;
     // (2) the output ring of width 2: exact gather (reflection at the borders of the upsampled image)
     p.w = w;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ho = g.Ho; p.Wo = g.Wo; p.k = 5; p.s = 1; p.p = 2; p.up = 1; p.Hu = g.Hu; p.Wu = g.Wu;
     p.M = g.M; p.K = g.K; p.ring = 2; p.phases = 0;
-    p.part = wp + (size_t)4 * g.Co * 9 * g.Ci;   // the partial buffer follows the merged phase weights (conv_up5_scratch_bytes)
+    p.part = (float*)((char*)wp + up5_merged_bytes(g));   // the partial buffer follows the merged phase weights
     return launch_fwd_fast<WM, WN, TM, TN>(g, p, st);
 }
 
@@ -942,12 +951,16 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
     const bool kc = wgrad_kc_ok(g);
     void* part = (char*)dwp + up5_dwp_bytes(g);      // partial tiles of the ordered-slice kernels follow the phase gradients
     WgFP p;
-    p.fsl = 0; p.fs_x = p.fs_dy = 0;
+    p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_dy = 0;
     p.x = x; p.dy = dy; p.dw = dwp; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.Co = g.Co; p.k = 3; p.s = 1; p.p = 0;
     p.up = 0; p.Hu = g.Hi; p.Wu = g.Wi; p.P = g.B * p.Ho * p.Wo; p.Kn = 9 * g.Ci; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
     p.B = g.B; p.ring = 0; p.phases = 1; p.Hf = g.Ho; p.Wf = g.Wo;
-    int rc = kc ? launch_wgrad_kc_any(g, p, part, st) : launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
+    int rc;
+    if (kc && conv_up5_wino_wgrad_scratch_bytes(g)) {     // Winograd: the four phase gradients in one batched A^T B GEMM
+        void* wino_scr = (char*)dwp + ((wgrad_part_scratch(g, BK, WGKC_TARGET) + 255) & ~(size_t)255);
+        rc = conv_up5_wino_wgrad_phases(g, x, dy, dwp, db, wino_scr, st);
+    } else rc = kc ? launch_wgrad_kc_any(g, p, part, st) : launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
     if (rc) return rc;
     // (2) fold the 4 x 3x3 phase gradients back onto the 5x5 filter
     const int64_t ns = (int64_t)g.Co * 25 * (g.Ci / 4);
@@ -977,7 +990,10 @@ int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, i
     p.Hc = g.Hi; p.Wc = g.Wi; p.Mc = 0; p.tiles_n = 0; p.nwg = 0; p.ksplit = 1;
     p.mode = 1; p.pad = 0; p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi;
     p.dyv = 1; p.Hf = g.Ho; p.Wf = g.Wo; p.band = 0; p.upshift = 0; p.Hd = g.Hi; p.Wd = g.Wi;
-    for (int ph = 0; ph < 4; ++ph) {
+    if (conv_up5_wino_ok(g)) {       // Winograd: full correlation of the four phase views of dy with the flipped merged filters
+        const int rc = conv_up5_wino_dgrad_phases(g, dy, wp, dx, accumulate, (char*)wp + up5_merged_bytes(g), st);
+        if (rc) return rc;
+    } else for (int ph = 0; ph < 4; ++ph) {
         p.w = wp + (size_t)ph * g.Co * 9 * g.Ci;
         p.py = ph >> 1; p.px = ph & 1;
         p.accumulate = (ph > 0 || accumulate) ? 1 : 0;
@@ -999,19 +1015,24 @@ int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, i
 size_t conv_up5_scratch_bytes(const ConvGeom& g) {
     return up5_eligible(g) ? (size_t)4 * g.Co * 9 * g.Ci * sizeof(float) : 0;
 }
+// dgrad of a sub-pixel layer: merged phase filters, then the Winograd planes of its four phases
+size_t conv_up5_dgrad_scratch_bytes(const ConvGeom& g) {
+    if (!fast_enabled() || !up5_eligible(g)) return 0;
+    return up5_merged_bytes(g) + conv_up5_wino_dgrad_scratch_bytes(g);
+}
 // weight-gradient scratch of the tuned kernels: phase gradients of the sub-pixel layers + the partial tiles of the
 // ordered-slice kernel (0 when neither applies)
 size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled()) return 0;
     if (wgrad_kc_ok(g) && conv_wino_ok(g)) return conv_wgrad_wino_scratch_bytes(g);
-    if (wgrad_kc_ok(g)) return wgrad_part_scratch(g, BK, WGKC_TARGET);
+    if (wgrad_kc_ok(g)) return ((wgrad_part_scratch(g, BK, WGKC_TARGET) + 255) & ~(size_t)255) + (up5_eligible(g) ? conv_up5_wino_wgrad_scratch_bytes(g) : 0);
     return conv_up5_scratch_bytes(g);
 }
 // forward scratch: merged phase weights + ring split-K partials (sub-pixel layers), or the split-K partials of a small-grid layer
 size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled()) return 0;
     if (conv_wino_ok(g)) return conv_wino_scratch_bytes(g);
-    if (up5_eligible(g)) return conv_up5_scratch_bytes(g) + fwd_partial_bytes(g, 2, BK);
+    if (up5_eligible(g)) return up5_merged_bytes(g) + ((fwd_partial_bytes(g, 2, BK) + 255) & ~(size_t)255) + conv_up5_wino_fwd_scratch_bytes(g);
     return fwd_partial_bytes(g, 0, BK);
 }
 
@@ -1042,7 +1063,7 @@ int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw
 
 // C_f[T][N] = A_f[T][K] x B_f[N][K]^T for f = 0 .. nslices-1 (fp32, exact MFMA): the tuned forward kernel run as a 1x1 "conv" over a
 // T x 1 "image", slice f on blockIdx.y.  K % 16 == 0.  Used by the Winograd path (conv_wino.hip).
-int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, hipStream_t st) {
+int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, int a_mod, hipStream_t st) {
     if (K % 16 != 0 || T <= 0 || N <= 0) { set_error("gemm_slices_f32: bad shape"); return ACLGAN_EINVAL; }
     FwdFP p;
     p.part = nullptr; p.rows = 0; p.w16 = nullptr; p.x16 = nullptr;
@@ -1050,7 +1071,7 @@ int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, in
     p.Hi = T; p.Wi = 1; p.Ci = K; p.Ho = T; p.Wo = 1; p.Co = N; p.k = 1; p.s = 1; p.p = 0;
     p.up = 0; p.Hu = T; p.Wu = 1; p.M = T; p.K = K; p.act = ACLGAN_ACT_NONE; p.tiles_n = 0; p.nwg = 0; p.nkz = K / BK;
     p.B = 1; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
-    p.fsl = nslices; p.fs_x = (long long)T * K; p.fs_w = (long long)N * K; p.fs_y = (long long)T * N;
+    p.fsl = nslices; p.fsx_mod = a_mod; p.fs_x = (long long)T * K; p.fs_w = (long long)N * K; p.fs_y = (long long)T * N;
     if (N > 64) {
         p.tiles_n = cdiv(N, 128); p.nwg = cdiv(T, 128) * p.tiles_n;
         static int occ3 = -1;
@@ -1073,7 +1094,7 @@ int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float
     if (!fast_enabled() || g.Ci % 16 != 0) return ACLGAN_EUNSUPPORTED;
     if (scratch && conv_wino_ok(g)) return conv_fwd_wino(g, x, w, bias, y, scratch, st);   // 3x3 ResBlock convs: Winograd F(4x4,3x3)
     FwdFP p;
-    p.fsl = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
+    p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
     p.part = (float*)scratch; p.rows = 0;
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
@@ -1110,14 +1131,14 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
 size_t gemm_at_b_slices_scratch(int T, int M, int N, int nslices) {
     return wgrad_partial_bytes(wgrad_plan(M, N, N, T, nslices, BK, WGKC_TARGET), M, nslices) + 256;
 }
-int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int M, int N, int nslices, void* part, hipStream_t st) {
+int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int M, int N, int nslices, int b_mod, void* part, hipStream_t st) {
     if (M % 64 != 0 || N % 64 != 0 || T <= 0) { set_error("gemm_at_b_slices_f32: bad shape"); return ACLGAN_EINVAL; }
     WgFP p;
     p.x = Bm; p.dy = A; p.dw = Cm; p.db = nullptr;
     p.Hi = T; p.Wi = 1; p.Ci = N; p.Ho = T; p.Wo = 1; p.Co = M; p.k = 1; p.s = 1; p.p = 0;
     p.up = 0; p.Hu = T; p.Wu = 1; p.P = T; p.Kn = N; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
     p.B = 1; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
-    p.fsl = nslices; p.fs_x = (long long)T * N; p.fs_dy = (long long)T * M;
+    p.fsl = nslices; p.fsx_mod = b_mod; p.fs_x = (long long)T * N; p.fs_dy = (long long)T * M;
     ConvGeom g;
     memset(&g, 0, sizeof g);
     g.Co = M; g.Ci = N;
@@ -1127,7 +1148,7 @@ int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int 
 int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
     if (!fast_enabled() || g.Co % 4 != 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     WgFP p;
-    p.fsl = 0; p.fs_x = p.fs_dy = 0;
+    p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_dy = 0;
     p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.P = g.M; p.Kn = g.K; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;

@@ -735,7 +735,7 @@ size_t up5_w16_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * 
 FwdFP fwd_params(const ConvGeom& g, const float* x, const u16* w16, const float* bias, float* y, const u16* x16 = nullptr) {
     FwdFP p;
     p.part = nullptr; p.rows = 0; p.w = nullptr; p.w16 = w16; p.x16 = x16;
-    p.fsl = 0; p.fs_x = p.fs_w = p.fs_y = 0;
+    p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0;
     p.x = x; p.bias = bias; p.y = y;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.M = g.M; p.K = g.K; p.act = g.act; p.tiles_n = 0; p.nwg = 0; p.nkz = 0;
@@ -863,7 +863,7 @@ int dgrad16_t(const ConvGeom& g, const float* dy, const float* w, const u16* w16
 
 WgFP wg_params(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db) {
     WgFP p;
-    p.fsl = 0; p.fs_x = p.fs_dy = 0;
+    p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_dy = 0;
     p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.P = g.M; p.Kn = g.K; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;

@@ -63,6 +63,7 @@ struct FwdFP {
     // batched plain GEMMs (the 36 frequency planes of the Winograd path): blockIdx.y = slice f, operands / result of slice f start
     // fs_* floats after those of slice 0.  0 = off.
     int fsl; long long fs_x, fs_w, fs_y;
+    int fsx_mod;                 // > 0: the x operand of slice f is plane f % fsx_mod
 };
 
 __device__ __forceinline__ bool fwd_row(const FwdFP& p, int m, int& b, int& oy, int& ox) {
@@ -242,6 +243,7 @@ struct WgFP {
     // batched plain "A^T B" GEMMs (the 36 frequency planes of the Winograd weight gradient): blockIdx.y = slice f; x / dy of slice
     // f start fs_x / fs_dy floats after those of slice 0; the result goes to dw + f*Co*Kn (like a phase).  0 = off.
     int fsl; long long fs_x, fs_dy;
+    int fsx_mod;                 // > 0: the x operand of slice f is plane f % fsx_mod
 };
 
 __device__ __forceinline__ void wg_coord(const WgFP& p, int pix, int& b, int& oy, int& ox) {
@@ -380,6 +382,7 @@ static size_t wgrad_partial_bytes(const WgPlan& q, int Co, int ny) {
     if (q.splits <= 1 && ny == 1) return 0;      // (phase launches always go through the partials: 4 phases share one db)
     return ((size_t)q.splits * ny * q.nwg * q.BM * q.BN + (size_t)q.splits * ny * Co) * sizeof(float);
 }
+static size_t up5_merged_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * sizeof(float) + 255) & ~(size_t)255; }
 static size_t up5_dwp_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * sizeof(float) + 255) & ~(size_t)255; }
 static int up5_ring_pixels(const ConvGeom& g) { return g.B * (g.Ho * g.Wo - (g.Ho - 4) * (g.Wo - 4)); }
 // scratch of a partial-store weight gradient of layer g: [dwp (sub-pixel layers)][partials]

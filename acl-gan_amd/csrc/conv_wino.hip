@@ -22,9 +22,10 @@
 
 namespace aclgan {
 
-int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, hipStream_t st);   // conv_fast.hip
+// conv_fast.hip.  a_mod / b_mod > 0: the A (resp. B) operand of slice f is plane f % mod (the four sub-pixel phases share one input transform)
+int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, int a_mod, hipStream_t st);
 size_t gemm_at_b_slices_scratch(int T, int M, int N, int nslices);
-int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int M, int N, int nslices, void* part, hipStream_t st);
+int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int M, int N, int nslices, int b_mod, void* part, hipStream_t st);
 
 namespace {
 
@@ -70,6 +71,8 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
     // dgrad (row = cin, k = cout, flipped taps) reads w with stride 9*Cin -- 9 strided loads per thread against 36 coalesced stores
     const int R = flip ? Ci : Co, K = flip ? Co : Ci;
     const int64_t n = (int64_t)R * K;
+    w += (size_t)blockIdx.y * Co * 9 * Ci;        // blockIdx.y = phase (merged filters of the sub-pixel layers), else 0
+    U += (size_t)blockIdx.y * 36 * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int kk = (int)(i % K), row = (int)(i / K);
         const int co = flip ? kk : row, ci = flip ? row : kk;
@@ -97,10 +100,24 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
     }
 }
 
-// V[f][t][c] = (B^T d B)[f] of the 6x6 input patch of tile t = (b, ty, tx): rows 4ty-1 .. 4ty+4 (reflect or zero padding)
-__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int zero_pad) {
-    const int TY = H >> 2, TX = W >> 2;
+// A strided window onto an NHWC tensor [B][HS][WS][C]: logical pixel (iy, ix), 0 <= iy < H, 0 <= ix < W, lives at physical
+// row oy0 + sy*iy, column ox0 + sx*ix.  Identity view = the tensor itself; the sub-pixel phases of the upsample+5x5 layers are
+// the views (sy = sx = 2, oy0 = 2 + py, ox0 = 2 + px) of the hi-res map (conv_fast.hip: up5_*).
+struct WView { int H, W, sy, sx, oy0, ox0, HS, WS; };
+struct WViews { WView v[4]; int nph; };
+__host__ __device__ __forceinline__ size_t vaddr(const WView& v, int b, int iy, int ix, int C) {
+    return ((size_t)(b * v.HS + v.oy0 + v.sy * iy) * v.WS + v.ox0 + v.sx * ix) * C;
+}
+WView ident_view(int H, int W) { WView v = {H, W, 1, 1, 0, 0, H, W}; return v; }
+WView phase_view(int Hv, int Wv, int py, int px, int Hf, int Wf) { WView v = {Hv, Wv, 2, 2, 2 + py, 2 + px, Hf, Wf}; return v; }
+
+// V[ph][f][t][c] = (B^T d B)[f] of the 6x6 patch of tile t = (b, ty, tx) of view ph: logical rows 4ty+off .. 4ty+off+5; positions
+// outside the view are reflected (reflect = 1: the forward's ReflectionPad2d) or read as zero.  blockIdx.y = phase.
+__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, WViews vs, int C, int TY, int TX, int off,
+                                                         int reflect) {
+    const WView v = vs.v[blockIdx.y];
     const int64_t T = (int64_t)B * TY * TX, n = T * C;
+    float* Vp = V + (size_t)blockIdx.y * 36 * T * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int64_t t = i / C;
@@ -109,16 +126,16 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 6; ++j) {              // columns of the patch: B^T d
             float d[6];
-            const int ixr = 4 * tx - 1 + j;
-            const bool xin = (unsigned)ixr < (unsigned)W;
-            const int ix = reflw(ixr, W);
+            const int ixr = 4 * tx + off + j;
+            const bool xin = (unsigned)ixr < (unsigned)v.W;
+            const int ix = reflect ? reflw(ixr, v.W) : (xin ? ixr : 0);
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const int iyr = 4 * ty - 1 + r;
-                const bool in = xin && (unsigned)iyr < (unsigned)H;
-                const int iy = reflw(iyr, H);
-                const float v = x[((size_t)(b * H + iy) * W + ix) * C + c];
-                d[r] = (zero_pad && !in) ? 0.f : v;
+                const int iyr = 4 * ty + off + r;
+                const bool yin = (unsigned)iyr < (unsigned)v.H;
+                const int iy = reflect ? reflw(iyr, v.H) : (yin ? iyr : 0);
+                const float val = x[vaddr(v, b, iy, ix, C) + c];
+                d[r] = (reflect || (xin && yin)) ? val : 0.f;
             }
             float o[6];
             bt6(d, o);
@@ -130,42 +147,72 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
             float o[6];
             bt6(tmp[r], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) V[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
+            for (int j = 0; j < 6; ++j) Vp[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
         }
     }
 }
 
-// y[b][4ty+i][4tx+j][c] (+)= act((A^T M A)[i][j] + bias[c])
-__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y, int B, int H,
-                                                          int W, int C, int act, int accumulate) {
-    const int TY = H >> 2, TX = W >> 2;
+// sum = 0: y through view ph  (+)= act((A^T M_ph A) + bias), one view per phase (forward: the phases interleave into the hi-res map);
+// sum = 1: y through view 0   (+)= sum over the nph phases of A^T M_ph A  (dgrad: all phases land on the same low-res dx).
+// Outputs beyond the view's logical extent (ragged last tiles) are dropped.
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y, int B, WViews vs,
+                                                          int C, int TY, int TX, int act, int accumulate, int sum) {
     const int64_t T = (int64_t)B * TY * TX, n = T * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int64_t t = i / C;
         const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
-        float tmp[4][6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {              // columns: A^T M
-            float m[6];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) m[r] = M[((size_t)(r * 6 + j) * T + t) * C + c];
-            float o[4];
-            at4(m, o);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tmp[r][j] = o[r];
-        }
         const float bv = bias ? bias[c] : 0.f;
+        float tot[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {              // rows: (A^T M) A
-            float o[4];
-            at4(tmp[r], o);
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float* dst = y + ((size_t)(b * H + 4 * ty + r) * W + 4 * tx + j) * C + c;
-                const float v = actw(o[j] + bv, act);
-                *dst = accumulate ? *dst + v : v;
+            for (int j = 0; j < 4; ++j) tot[r][j] = 0.f;
+        for (int ph = 0; ph < vs.nph; ++ph) {
+            const float* Mp = M + (size_t)ph * 36 * T * C;
+            float tmp[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {              // columns: A^T M
+                float m[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) m[r] = Mp[((size_t)(r * 6 + j) * T + t) * C + c];
+                float o[4];
+                at4(m, o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmp[r][j] = o[r];
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {              // rows: (A^T M) A
+                float o[4];
+                at4(tmp[r], o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (sum) tot[r][j] += o[j];
+                    else {
+                        const WView v = vs.v[ph];
+                        const int oy = 4 * ty + r, ox = 4 * tx + j;
+                        if (oy < v.H && ox < v.W) {
+                            float* dst = y + vaddr(v, b, oy, ox, C) + c;
+                            const float val = actw(o[j] + bv, act);
+                            *dst = accumulate ? *dst + val : val;
+                        }
+                    }
+                }
+            }
+        }
+        if (sum) {
+            const WView v = vs.v[0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int oy = 4 * ty + r, ox = 4 * tx + j;
+                    if (oy < v.H && ox < v.W) {
+                        float* dst = y + vaddr(v, b, oy, ox, C) + c;
+                        const float val = actw(tot[r][j] + bv, act);
+                        *dst = accumulate ? *dst + val : val;
+                    }
+                }
         }
     }
 }
@@ -185,12 +232,14 @@ __device__ __forceinline__ void gt3(const float (&u)[6], float (&g)[3]) {    // 
     g[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
 }
 
-// dM[f][t][c] = (A dY A^T)[f] of the 4x4 output-gradient tile t; bpart[j][c] (optional) = this thread's column sum of dy (bias
-// gradient, reduced in order by wino_bias_finish_kernel).  Launch with gridDim.x * 256 a multiple of C: a thread keeps ONE channel.
-__global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ bpart, int B, int H, int W,
-                                                           int C) {
-    const int TY = H >> 2, TX = W >> 2;
+// dM[ph][f][t][c] = (A dY A^T)[f] of the 4x4 tile t of the output gradient seen through view ph (zero outside the view);
+// bpart[ph][j][c] (optional) = this thread's column sum of dy (bias gradient, reduced in order by wino_bias_finish_kernel).
+// Launch with gridDim.x * 256 a multiple of C: a thread keeps ONE channel.  blockIdx.y = phase.
+__global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ bpart, int B, WViews vs,
+                                                           int C, int TY, int TX) {
+    const WView v = vs.v[blockIdx.y];
     const int64_t T = (int64_t)B * TY * TX;
+    float* dMp = dM + (size_t)blockIdx.y * 36 * T * C;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
     const int c = (int)(gid % C);
     float bs = 0.f;
@@ -199,11 +248,17 @@ __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restri
         float tmp[6][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {              // columns: A dY
-            float v[4];
+            float q[4];
+            const int ox = 4 * tx + j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = dy[((size_t)(b * H + 4 * ty + r) * W + 4 * tx + j) * C + c]; bs += v[r]; }
+            for (int r = 0; r < 4; ++r) {
+                const int oy = 4 * ty + r;
+                const bool in = oy < v.H && ox < v.W;
+                q[r] = in ? dy[vaddr(v, b, in ? oy : 0, in ? ox : 0, C) + c] : 0.f;
+                bs += q[r];
+            }
             float o[6];
-            a6(v, o);
+            a6(q, o);
 #pragma unroll
             for (int r = 0; r < 6; ++r) tmp[r][j] = o[r];
         }
@@ -212,10 +267,10 @@ __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restri
             float o[6];
             a6(tmp[r], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) dM[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
+            for (int j = 0; j < 6; ++j) dMp[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
         }
     }
-    if (bpart) bpart[gid] = bs;                    // [gid / C][c]
+    if (bpart) bpart[(size_t)blockIdx.y * nth + gid] = bs;     // [ph][gid / C][c]
 }
 // db[c] += sum over the partial rows, in a fixed order: 16 channels x 16 row groups per workgroup, groups combined through LDS
 __global__ void __launch_bounds__(256) wino_bias_finish_kernel(const float* __restrict__ bpart, int rows, int C, float* __restrict__ db) {
@@ -245,6 +300,8 @@ __global__ void __launch_bounds__(256) wino_bias_finish_kernel(const float* __re
 // dw[co][ky][kx][ci] += (G^T dU G)[ky][kx] of dU[f][co][ci]
 __global__ void __launch_bounds__(256) wino_filtergrad_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci) {
     const int64_t n = (int64_t)Co * Ci;
+    dU += (size_t)blockIdx.y * 36 * n;            // blockIdx.y = phase
+    dw += (size_t)blockIdx.y * 9 * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int ci = (int)(i % Ci), co = (int)(i / Ci);
         float t[3][6];
@@ -273,30 +330,26 @@ bool wino_enabled() {
     if (v < 0) { const char* e = getenv("ACLGAN_NOWINO"); v = (e && atoi(e)) ? 0 : 1; }
     return v == 1;
 }
+bool wino_up5_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_NOWINOUP5"); v = (e && atoi(e)) ? 0 : 1; }
+    return v == 1;
+}
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+int grid_for(int64_t n, int cap) { return (int)std::min<int64_t>(cdiv64(n, 256), cap); }
+const int WINO_BIAS_BLOCKS = 1024;       // x 256 threads: a multiple of every channel count in {64, 128, 256, 512}
 
-// the pipeline: filter transform -> input transform -> 36 GEMMs -> output transform.  `in` has Cin_ channels, `out` Cout_.
-int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* w, int w_co, int w_ci, int flip, const float* bias, float* out,
-             int act, int accumulate, int zero_pad, void* scratch, hipStream_t st) {
-    const int64_t T = (int64_t)B * (H / 4) * (W / 4);
-    float* U = (float*)scratch;
-    float* V = (float*)((char*)scratch + align256((size_t)36 * Cout_ * Cin_ * sizeof(float)));
-    float* M = (float*)((char*)V + align256((size_t)36 * T * Cin_ * sizeof(float)));
-    hipLaunchKernelGGL(wino_filter_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)w_co * w_ci, 256), 4096)), dim3(256), 0, st, w, U, w_co, w_ci, flip);
-    ACL_CHECK_LAUNCH("wino_filter_kernel");
-    hipLaunchKernelGGL(wino_input_kernel, dim3((int)std::min<int64_t>(cdiv64(T * Cin_, 256), 16384)), dim3(256), 0, st, in, V, B, H, W, Cin_, zero_pad);
-    ACL_CHECK_LAUNCH("wino_input_kernel");
-    const int rc = gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((int)std::min<int64_t>(cdiv64(T * Cout_, 256), 16384)), dim3(256), 0, st, M, bias, out, B, H, W, Cout_, act,
-                       accumulate);
-    ACL_CHECK_LAUNCH("wino_output_kernel");
-    return ACLGAN_OK;
-}
+WViews one_view(const WView& v) { WViews w; w.v[0] = v; w.v[1] = v; w.v[2] = v; w.v[3] = v; w.nph = 1; return w; }
+
+// carve `bytes` (256-aligned) off a scratch cursor
+float* take(char*& cur, size_t bytes) { float* p = (float*)cur; cur += align256(bytes); return p; }
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// 3x3 stride-1 reflect-pad-1 layers (ResBlocks)
+// ------------------------------------------------------------------------------------------
 // 3x3, stride 1, reflect pad 1, no upsample, 4x4-tileable output, channel counts the GEMM kernel takes, and enough channels to pay
 bool conv_wino_ok(const ConvGeom& g) {
     return wino_enabled() && g.k == 3 && g.s == 1 && g.p == 1 && g.up == 0 && g.Ho % 4 == 0 && g.Wo % 4 == 0 && g.Ci % 16 == 0 && g.Co % 16 == 0 &&
@@ -308,20 +361,39 @@ size_t conv_wino_scratch_bytes(const ConvGeom& g) {
     const int cmax = std::max(g.Ci, g.Co);      // forward: V has Cin, M has Cout channels; dgrad the other way round
     return align256((size_t)36 * g.Co * g.Ci * sizeof(float)) + 2 * align256((size_t)36 * T * cmax * sizeof(float)) + 256;
 }
+namespace {
+// filter transform -> input transform -> 36 GEMMs -> output transform.  `in` has Cin_ channels, `out` Cout_.
+int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* w, int w_co, int w_ci, int flip, const float* bias, float* out,
+             int act, int accumulate, int reflect, void* scratch, hipStream_t st) {
+    const int TY = H / 4, TX = W / 4;
+    const int64_t T = (int64_t)B * TY * TX;
+    char* cur = (char*)scratch;
+    float* U = take(cur, (size_t)36 * Cout_ * Cin_ * 4);
+    float* V = take(cur, (size_t)36 * T * Cin_ * 4);
+    float* M = take(cur, (size_t)36 * T * Cout_ * 4);
+    const WViews vw = one_view(ident_view(H, W));
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip);
+    ACL_CHECK_LAUNCH("wino_filter_kernel");
+    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * Cin_, 16384), 1), dim3(256), 0, st, in, V, B, vw, Cin_, TY, TX, -1, reflect);
+    ACL_CHECK_LAUNCH("wino_input_kernel");
+    const int rc = gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(T * Cout_, 16384)), dim3(256), 0, st, M, bias, out, B, vw, Cout_, TY, TX, act, accumulate, 0);
+    ACL_CHECK_LAUNCH("wino_output_kernel");
+    return ACLGAN_OK;
+}
+}  // namespace
 int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st) {
     if (!conv_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
-    return wino_run(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, w, g.Co, g.Ci, 0, bias, y, g.act, 0, 0, scratch, st);
+    return wino_run(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, w, g.Co, g.Ci, 0, bias, y, g.act, 0, 1, scratch, st);
 }
 // the INTERIOR of the padded-grid gradient (= dx without the mirrored halo contributions): dx (+)= dy (*) flipped w^T, zero padding
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st) {
     if (!conv_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
-    return wino_run(g.B, g.Hi, g.Wi, g.Co, g.Ci, dy, w, g.Co, g.Ci, 1, nullptr, dx, ACLGAN_ACT_NONE, accumulate, 1, scratch, st);
+    return wino_run(g.B, g.Hi, g.Wi, g.Co, g.Ci, dy, w, g.Co, g.Ci, 1, nullptr, dx, ACLGAN_ACT_NONE, accumulate, 0, scratch, st);
 }
 
 // weight (and bias) gradient.  scratch: V [36][T][Cin] | dM [36][T][Cout] | dU [36][Cout][Cin] | bias partials | GEMM partial tiles
-namespace {
-const int WINO_BIAS_BLOCKS = 1024;       // x 256 threads: a multiple of every channel count in {64, 128, 256, 512}
-}
 size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
@@ -331,16 +403,18 @@ size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g) {
 int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
     if ((WINO_BIAS_BLOCKS * 256) % g.Co != 0) return ACLGAN_EUNSUPPORTED;
-    const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
-    char* s = (char*)scratch;
-    float* V = (float*)s;  s += align256((size_t)36 * T * g.Ci * 4);
-    float* dM = (float*)s; s += align256((size_t)36 * T * g.Co * 4);
-    float* dU = (float*)s; s += align256((size_t)36 * g.Co * g.Ci * 4);
-    float* bpart = (float*)s; s += align256((size_t)WINO_BIAS_BLOCKS * 256 * 4);
-    void* part = s;
-    hipLaunchKernelGGL(wino_input_kernel, dim3((int)std::min<int64_t>(cdiv64(T * g.Ci, 256), 16384)), dim3(256), 0, st, x, V, g.B, g.Hi, g.Wi, g.Ci, 0);
+    const int TY = g.Ho / 4, TX = g.Wo / 4;
+    const int64_t T = (int64_t)g.B * TY * TX;
+    char* cur = (char*)scratch;
+    float* V = take(cur, (size_t)36 * T * g.Ci * 4);
+    float* dM = take(cur, (size_t)36 * T * g.Co * 4);
+    float* dU = take(cur, (size_t)36 * g.Co * g.Ci * 4);
+    float* bpart = take(cur, (size_t)WINO_BIAS_BLOCKS * 256 * 4);
+    void* part = cur;
+    const WViews vw = one_view(ident_view(g.Hi, g.Wi));
+    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * g.Ci, 16384), 1), dim3(256), 0, st, x, V, g.B, vw, g.Ci, TY, TX, -1, 1);
     ACL_CHECK_LAUNCH("wino_input_kernel");
-    hipLaunchKernelGGL(wino_outgrad_kernel, dim3(WINO_BIAS_BLOCKS), dim3(256), 0, st, dy, dM, db ? bpart : (float*)nullptr, g.B, g.Ho, g.Wo, g.Co);
+    hipLaunchKernelGGL(wino_outgrad_kernel, dim3(WINO_BIAS_BLOCKS, 1), dim3(256), 0, st, dy, dM, db ? bpart : (float*)nullptr, g.B, vw, g.Co, TY, TX);
     ACL_CHECK_LAUNCH("wino_outgrad_kernel");
     if (db) {
         hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, WINO_BIAS_BLOCKS * 256 / g.Co, g.Co, db);
@@ -348,10 +422,115 @@ int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* d
     }
     hipError_t e = hipMemsetAsync(dU, 0, (size_t)36 * g.Co * g.Ci * sizeof(float), st);
     if (e != hipSuccess) return hip_fail(e, "memset dU");
-    const int rc = gemm_at_b_slices_f32(dM, V, dU, (int)T, g.Co, g.Ci, 36, part, st);
+    const int rc = gemm_at_b_slices_f32(dM, V, dU, (int)T, g.Co, g.Ci, 36, 0, part, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_filtergrad_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)g.Co * g.Ci, 256), 4096)), dim3(256), 0, st, dU, dw, g.Co, g.Ci);
+    hipLaunchKernelGGL(wino_filtergrad_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 1), dim3(256), 0, st, dU, dw, g.Co, g.Ci);
     ACL_CHECK_LAUNCH("wino_filtergrad_kernel");
+    return ACLGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// the four sub-pixel phases of "Upsample(2) + ReflectionPad2d(2) + Conv2d(5x5)" (conv_fast.hip: up5_*): each phase is a VALID 3x3
+// convolution of the low-res input with a merged filter wp[phase] -- i.e. Winograd material.  All four phases share the input
+// transform (forward, wgrad) and run as ONE batched GEMM launch of 4 x 36 = 144 slices.  The output ring of width 2 keeps the exact
+// gather kernels (launched by the caller).  ACLGAN_NOWINOUP5=1 keeps the direct phase kernels.
+// ------------------------------------------------------------------------------------------
+bool conv_up5_wino_ok(const ConvGeom& g) {
+    return wino_enabled() && wino_up5_enabled() && g.up == 1 && g.k == 5 && g.p == 2 && g.s == 1 && g.Hi >= 6 && g.Wi >= 6 && g.Ci % 16 == 0 &&
+           g.Co % 16 == 0 && (int64_t)g.Ci * g.Co >= 64 * 64;
+}
+namespace {
+struct Up5Geo { int Hv, Wv, TY, TX, TYd, TXd; int64_t T, Td; WViews ph; };
+Up5Geo up5_geo(const ConvGeom& g) {
+    Up5Geo q;
+    q.Hv = g.Hi - 2; q.Wv = g.Wi - 2;                       // VALID outputs per phase
+    q.TY = cdiv(q.Hv, 4); q.TX = cdiv(q.Wv, 4); q.T = (int64_t)g.B * q.TY * q.TX;
+    q.TYd = cdiv(g.Hi, 4); q.TXd = cdiv(g.Wi, 4); q.Td = (int64_t)g.B * q.TYd * q.TXd;       // dgrad tiles the low-res dx
+    for (int p = 0; p < 4; ++p) q.ph.v[p] = phase_view(q.Hv, q.Wv, p >> 1, p & 1, g.Ho, g.Wo);
+    q.ph.nph = 4;
+    return q;
+}
+}  // namespace
+// forward: U [4][36][Co][Ci] | V [36][T][Ci] | M [4][36][T][Co]
+size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g) {
+    if (!conv_up5_wino_ok(g)) return 0;
+    const Up5Geo q = up5_geo(g);
+    return align256((size_t)144 * g.Co * g.Ci * 4) + align256((size_t)36 * q.T * g.Ci * 4) + align256((size_t)144 * q.T * g.Co * 4) + 256;
+}
+int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st) {
+    if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
+    const Up5Geo q = up5_geo(g);
+    char* cur = (char*)scratch;
+    float* U = take(cur, (size_t)144 * g.Co * g.Ci * 4);
+    float* V = take(cur, (size_t)36 * q.T * g.Ci * 4);
+    float* M = take(cur, (size_t)144 * q.T * g.Co * 4);
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0);
+    ACL_CHECK_LAUNCH("wino_filter_kernel(up5)");
+    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(q.T * g.Ci, 16384), 1), dim3(256), 0, st, x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), g.Ci, q.TY, q.TX, 0, 0);
+    ACL_CHECK_LAUNCH("wino_input_kernel(up5)");
+    const int rc = gemm_slices_f32(V, U, M, (int)q.T, g.Ci, g.Co, 144, 36, st);      // the 4 phases share V: A offset = (f % 36) planes
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(q.T * g.Co, 16384)), dim3(256), 0, st, M, bias, y, g.B, q.ph, g.Co, q.TY, q.TX, g.act, 0, 0);
+    ACL_CHECK_LAUNCH("wino_output_kernel(up5)");
+    return ACLGAN_OK;
+}
+// dgrad: U' [4][36][Ci][Co] | V' [4][36][Td][Co] | M [4][36][Td][Ci];  dx (+)= sum over phases (full correlation with the flipped filter)
+size_t conv_up5_wino_dgrad_scratch_bytes(const ConvGeom& g) {
+    if (!conv_up5_wino_ok(g)) return 0;
+    const Up5Geo q = up5_geo(g);
+    return align256((size_t)144 * g.Co * g.Ci * 4) + align256((size_t)144 * q.Td * g.Co * 4) + align256((size_t)144 * q.Td * g.Ci * 4) + 256;
+}
+int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st) {
+    if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
+    const Up5Geo q = up5_geo(g);
+    char* cur = (char*)scratch;
+    float* U = take(cur, (size_t)144 * g.Co * g.Ci * 4);
+    float* V = take(cur, (size_t)144 * q.Td * g.Co * 4);
+    float* M = take(cur, (size_t)144 * q.Td * g.Ci * 4);
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1);
+    ACL_CHECK_LAUNCH("wino_filter_kernel(up5 dgrad)");
+    // dx[u] = sum_k wflip[k] dy_phase[u - 2 + k]: patches start 2 before the tile, zero outside the 62 x 62 phase view
+    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(q.Td * g.Co, 16384), 4), dim3(256), 0, st, dy, V, g.B, q.ph, g.Co, q.TYd, q.TXd, -2, 0);
+    ACL_CHECK_LAUNCH("wino_input_kernel(up5 dgrad)");
+    const int rc = gemm_slices_f32(V, U, M, (int)q.Td, g.Co, g.Ci, 144, 0, st);
+    if (rc) return rc;
+    WViews dst = one_view(ident_view(g.Hi, g.Wi));
+    dst.nph = 4;
+    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(q.Td * g.Ci, 16384)), dim3(256), 0, st, M, (const float*)nullptr, dx, g.B, dst, g.Ci, q.TYd, q.TXd,
+                       ACLGAN_ACT_NONE, accumulate, 1);
+    ACL_CHECK_LAUNCH("wino_output_kernel(up5 dgrad)");
+    return ACLGAN_OK;
+}
+// wgrad: V [36][T][Ci] | dM [4][36][T][Co] | dU [4][36][Co][Ci] | bias partials [4][...] | GEMM partial tiles;  dwp[phase] += G^T dU G
+size_t conv_up5_wino_wgrad_scratch_bytes(const ConvGeom& g) {
+    if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
+    const Up5Geo q = up5_geo(g);
+    return align256((size_t)36 * q.T * g.Ci * 4) + align256((size_t)144 * q.T * g.Co * 4) + align256((size_t)144 * g.Co * g.Ci * 4) +
+           align256((size_t)4 * WINO_BIAS_BLOCKS * 256 * 4) + gemm_at_b_slices_scratch((int)q.T, g.Co, g.Ci, 144) + 256;
+}
+int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st) {
+    if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || (WINO_BIAS_BLOCKS * 256) % g.Co != 0) return ACLGAN_EUNSUPPORTED;
+    const Up5Geo q = up5_geo(g);
+    char* cur = (char*)scratch;
+    float* V = take(cur, (size_t)36 * q.T * g.Ci * 4);
+    float* dM = take(cur, (size_t)144 * q.T * g.Co * 4);
+    float* dU = take(cur, (size_t)144 * g.Co * g.Ci * 4);
+    float* bpart = take(cur, (size_t)4 * WINO_BIAS_BLOCKS * 256 * 4);
+    void* part = cur;
+    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(q.T * g.Ci, 16384), 1), dim3(256), 0, st, x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), g.Ci, q.TY, q.TX, 0, 0);
+    ACL_CHECK_LAUNCH("wino_input_kernel(up5 wgrad)");
+    hipLaunchKernelGGL(wino_outgrad_kernel, dim3(WINO_BIAS_BLOCKS, 4), dim3(256), 0, st, dy, dM, db ? bpart : (float*)nullptr, g.B, q.ph, g.Co, q.TY, q.TX);
+    ACL_CHECK_LAUNCH("wino_outgrad_kernel(up5)");
+    if (db) {      // interior pixels (the four phases); the ring launch of the caller adds the ring pixels
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, 4 * WINO_BIAS_BLOCKS * 256 / g.Co, g.Co, db);
+        ACL_CHECK_LAUNCH("wino_bias_finish_kernel(up5)");
+    }
+    hipError_t e = hipMemsetAsync(dU, 0, (size_t)144 * g.Co * g.Ci * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail(e, "memset dU");
+    const int rc = gemm_at_b_slices_f32(dM, V, dU, (int)q.T, g.Co, g.Ci, 144, 36, part, st);     // V shared by the phases
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_filtergrad_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, dU, dwp, g.Co, g.Ci);
+    ACL_CHECK_LAUNCH("wino_filtergrad_kernel(up5)");
     return ACLGAN_OK;
 }
 
