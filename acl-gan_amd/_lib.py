@@ -112,6 +112,8 @@ SIGNATURES = {
     "aclgan_conv2d_wgrad_ws": (ci, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "aclgan_conv2d_wgrad_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_norm_fwd": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]),
+    "aclgan_conv2d_block_fwd": (ci, [C.POINTER(ConvDesc), ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
+    "aclgan_conv2d_block_fwd_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_norm_bwd": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp]),
     "aclgan_norm_scratch_bytes": (sz, [ci, ci, ci]),
     "aclgan_avgpool3s2_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp]),

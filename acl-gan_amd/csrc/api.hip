@@ -23,6 +23,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 using namespace aclgan;
 
+#include <algorithm>
 extern "C" {
 
 int aclgan_version(void) { return 200; }   // 0.2.0: 16-bit MFMA path, gradient buckets
@@ -41,6 +42,34 @@ int aclgan_conv2d_fwd_ws(const aclgan_conv_desc* d, const float* x, const float*
     if (rc) return rc;
     ACL_REQUIRE(x && w && y, "conv2d_fwd_ws: null buffer");
     return conv_fwd(g, x, w, bias, y, (hipStream_t)stream, scratch);
+}
+// Conv2dBlock.forward = conv + norm + activation (+ residual) as the engine runs it: where the forward kernel can, the normalisation
+// statistics come out of the conv epilogue (conv_fwd_stats_chunk) and the separate statistics pass is skipped
+static size_t block_stats_bytes(const ConvGeom& g) {
+    const int ch = conv_fwd_stats_chunk(g);
+    return ch ? (((size_t)2 * g.B * (g.Ho * g.Wo / ch) * g.Co * sizeof(float)) + 255) & ~(size_t)255 : 0;
+}
+size_t aclgan_conv2d_block_fwd_scratch_bytes(const aclgan_conv_desc* d) {
+    ConvGeom g;
+    if (make_geom(d, &g)) return 0;
+    return block_stats_bytes(g) + std::max(conv_fwd_scratch_bytes(g), norm_scratch_bytes(g.B, g.Ho * g.Wo, g.Co)) + 256;
+}
+int aclgan_conv2d_block_fwd(const aclgan_conv_desc* d, int norm_kind, int act, const float* x, const float* w, const float* bias, const float* nw,
+                            const float* nb, int n_stride, const float* residual, float* y_conv, float* y, float* mean, float* rstd, void* scratch,
+                            int* stats_fused, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(x && w && y_conv && y && mean && rstd && scratch, "conv2d_block_fwd: null buffer");
+    ACL_REQUIRE(d->act == ACLGAN_ACT_NONE, "conv2d_block_fwd: the activation follows the norm (pass it as `act`, desc.act must be none)");
+    const size_t sb = block_stats_bytes(g);
+    float* stats = sb ? (float*)scratch : nullptr;
+    void* rest = (char*)scratch + sb;
+    if (stats_fused) *stats_fused = stats ? 1 : 0;
+    rc = conv_fwd(g, x, w, bias, y_conv, (hipStream_t)stream, rest, stats);
+    if (rc) return rc;
+    return norm_fwd(norm_kind, act, g.B, g.Ho * g.Wo, g.Co, y_conv, nw, nb, n_stride, residual, y, mean, rstd, rest, (hipStream_t)stream, stats,
+                    conv_fwd_stats_chunk(g));
 }
 size_t aclgan_conv2d_fwd_scratch_bytes(const aclgan_conv_desc* d) {
     ConvGeom g;

@@ -38,7 +38,10 @@ int make_geom(const aclgan_conv_desc* d, ConvGeom* g);
 
 // ---- kernel launchers (all async on `st`) ----
 // scratch (optional, conv_fwd_scratch_bytes): enables the sub-pixel path of the upsample+5x5 decoder convs
-int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr);
+int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr);
+// > 0: conv_fwd (with scratch) can emit the normalisation statistics of its output from its epilogue: stats[B][Ho*Wo / chunk][Co] =
+// (mean, M2) of groups of `chunk` output pixels (the return value), the chunk partials norm_fwd combines;  0: not for this shape
+int conv_fwd_stats_chunk(const ConvGeom& g);
 size_t conv_fwd_scratch_bytes(const ConvGeom& g);
 size_t conv_up5_scratch_bytes(const ConvGeom& g);
 int conv_up5_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st);
@@ -51,7 +54,7 @@ int conv_up5_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx
 int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
 
 // tuned kernels (conv_fast.hip); return ACLGAN_EUNSUPPORTED when the shape is not eligible
-int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr);
+int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr);
 size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g);
 int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* dxp, float* dx, int accumulate, bool* direct, hipStream_t st);
 // also accumulates the bias gradient into db when db != nullptr
@@ -61,7 +64,7 @@ size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g);
 // Winograd F(4x4,3x3) path of the 3x3 stride-1 reflect-pad-1 layers (conv_wino.hip); EUNSUPPORTED when not eligible / no scratch
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_scratch_bytes(const ConvGeom& g);
-int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st);
+int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats = nullptr);
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);
 size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g);
 // the four VALID-3x3 phases of the sub-pixel upsample+5x5 path through Winograd (wp: merged fp32 phase filters [4][Co][3][3][Ci])
@@ -99,7 +102,8 @@ int conv_dgrad_small(const ConvGeom& g, const float* dy, const float* w, float* 
 
 size_t norm_scratch_bytes(int B, int HW, int C);
 int norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const float* w, const float* b, int w_stride,
-             const float* residual, float* y, float* mean, float* rstd, void* scratch, hipStream_t st);
+             const float* residual, float* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats = nullptr,
+             int stats_chunk = 0);
 int norm_bwd(int kind, int act, int B, int HW, int C, const float* x, const float* y, const float* dy,
              const float* w, int w_stride, const float* mean, const float* rstd, float* dx, float* dw, float* db,
              float* dres, int dres_accumulate, void* scratch, hipStream_t st);

@@ -242,7 +242,11 @@ static int launch_fwd(const ConvGeom& g, FwdP p, hipStream_t st) {
 
 size_t conv_fwd_scratch_bytes(const ConvGeom& g) { return conv_fwd_fast_scratch_bytes(g); }
 
-int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch) {
+int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch, float* stats) {
+    if (stats) {      // only offered where conv_fwd_stats_chunk(g) > 0
+        if (!scratch || !conv_fwd_stats_chunk(g)) { set_error("conv_fwd: this shape does not emit normalisation statistics"); return ACLGAN_EINVAL; }
+        return conv_fwd_fast(g, x, w, bias, y, st, scratch, stats);
+    }
     if (scratch) {
         const int rc = conv_up5_fwd(g, x, w, bias, y, scratch, st);
         if (rc != ACLGAN_EUNSUPPORTED) return rc;

@@ -1074,10 +1074,20 @@ int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, in
     p.fsl = nslices; p.fsx_mod = a_mod; p.fs_x = (long long)T * K; p.fs_w = (long long)N * K; p.fs_y = (long long)T * N;
     if (N > 64) {
         p.tiles_n = cdiv(N, 128); p.nwg = cdiv(T, 128) * p.tiles_n;
-        static int occ3 = -1;
-        if (occ3 < 0) { const char* e = getenv("ACLGAN_GEMM_OCC2"); occ3 = (e && atoi(e)) ? 0 : 1; }
-        if (occ3) hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2, 3>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+        // K is short here (the channel count): 128 x 128 tiles leave 1.5 rounds of workgroups and exposed prologues/epilogues;
+        // 64 x 128 tiles at 4 workgroups per CU measured 8 % faster on the ResBlock shape (profiles/r02_experiments.md).
+        // ACLGAN_GEMM_VAR=1: 128 x 64 tiles, 3 per CU;  =2: 128 x 128 tiles, 3 per CU.
+        static int var = -1;
+        if (var < 0) { const char* e = getenv("ACLGAN_GEMM_VAR"); var = e ? atoi(e) : 0; }
+        if (var == 1) {
+            p.tiles_n = cdiv(N, 64); p.nwg = cdiv(T, 128) * p.tiles_n;
+            hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 1, 3>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+        } else if (var == 2) {
+            hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2, 3>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+        } else {
+            p.tiles_n = cdiv(N, 128); p.nwg = cdiv(T, 64) * p.tiles_n;
+            hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 1, 2, 4>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+        }
     } else if (N > 32) {
         p.tiles_n = cdiv(N, 64); p.nwg = cdiv(T, 256) * p.tiles_n;
         hipLaunchKernelGGL((conv_fwd_fast_kernel<4, 1, 2, 2>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
@@ -1090,9 +1100,17 @@ int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, in
 }
 
 // returns ACLGAN_EUNSUPPORTED when the shape is not eligible (caller falls back to the general kernel)
-int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch) {
+// the Winograd output transform holds whole 4x4 output tiles per thread: it can emit the (mean, M2) partials of the following
+// normalisation layer at no extra pass over y.  ACLGAN_NOSTATFUSE=1 keeps the separate statistics kernel.
+int conv_fwd_stats_chunk(const ConvGeom& g) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ACLGAN_NOSTATFUSE"); off = (e && atoi(e)) ? 1 : 0; }
+    return (!off && fast_enabled() && g.Ci % 16 == 0 && g.act == ACLGAN_ACT_NONE && conv_wino_ok(g)) ? 16 : 0;
+}
+int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch, float* stats) {
     if (!fast_enabled() || g.Ci % 16 != 0) return ACLGAN_EUNSUPPORTED;
-    if (scratch && conv_wino_ok(g)) return conv_fwd_wino(g, x, w, bias, y, scratch, st);   // 3x3 ResBlock convs: Winograd F(4x4,3x3)
+    if (scratch && conv_wino_ok(g)) return conv_fwd_wino(g, x, w, bias, y, scratch, st, stats);   // 3x3 ResBlock convs: Winograd F(4x4,3x3)
+    if (stats) return ACLGAN_EUNSUPPORTED;
     FwdFP p;
     p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
     p.part = (float*)scratch; p.rows = 0;

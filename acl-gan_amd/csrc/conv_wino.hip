@@ -40,8 +40,20 @@ __device__ __forceinline__ float actw(float v, int act) {
     return v;
 }
 
+// the transform kernels move NV channels per thread (NHWC: NV consecutive floats = one 4 / 8 / 16-byte access)
+template <int NV> struct VecOf { typedef float T __attribute__((ext_vector_type(NV))); };
+template <> struct VecOf<1> { typedef float T; };
+template <int NV> __device__ __forceinline__ typename VecOf<NV>::T actv(typename VecOf<NV>::T v, int act) {
+    if (act == ACLGAN_ACT_NONE) return v;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = actw(v[e], act);
+    return v;
+}
+template <> __device__ __forceinline__ float actv<1>(float v, int act) { return actw(v, act); }
+
 // B^T d (input transform along one axis), G g (filter), A^T m (output)
-__device__ __forceinline__ void bt6(const float (&d)[6], float (&t)[6]) {
+template <typename F>
+__device__ __forceinline__ void bt6(const F (&d)[6], F (&t)[6]) {
     t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
     t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
     t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
@@ -49,7 +61,8 @@ __device__ __forceinline__ void bt6(const float (&d)[6], float (&t)[6]) {
     t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
     t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
-__device__ __forceinline__ void g6(const float (&g)[3], float (&u)[6]) {
+template <typename F>
+__device__ __forceinline__ void g6(const F (&g)[3], F (&u)[6]) {
     u[0] = 0.25f * g[0];
     u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
     u[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
@@ -57,7 +70,8 @@ __device__ __forceinline__ void g6(const float (&g)[3], float (&u)[6]) {
     u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
     u[5] = g[2];
 }
-__device__ __forceinline__ void at4(const float (&m)[6], float (&y)[4]) {
+template <typename F>
+__device__ __forceinline__ void at4(const F (&m)[6], F (&y)[4]) {
     y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
     y[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
     y[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
@@ -113,19 +127,22 @@ WView phase_view(int Hv, int Wv, int py, int px, int Hf, int Wf) { WView v = {Hv
 
 // V[ph][f][t][c] = (B^T d B)[f] of the 6x6 patch of tile t = (b, ty, tx) of view ph: logical rows 4ty+off .. 4ty+off+5; positions
 // outside the view are reflected (reflect = 1: the forward's ReflectionPad2d) or read as zero.  blockIdx.y = phase.
+template <int NV>
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, WViews vs, int C, int TY, int TX, int off,
                                                          int reflect) {
+    typedef typename VecOf<NV>::T F;
     const WView v = vs.v[blockIdx.y];
-    const int64_t T = (int64_t)B * TY * TX, n = T * C;
+    const int Cv = C / NV;
+    const int64_t T = (int64_t)B * TY * TX, n = T * Cv;
     float* Vp = V + (size_t)blockIdx.y * 36 * T * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int64_t t = i / C;
+        const int c = (int)(i % Cv) * NV;
+        const int64_t t = i / Cv;
         const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
-        float tmp[6][6];
+        F tmp[6][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {              // columns of the patch: B^T d
-            float d[6];
+            F d[6];
             const int ixr = 4 * tx + off + j;
             const bool xin = (unsigned)ixr < (unsigned)v.W;
             const int ix = reflect ? reflw(ixr, v.W) : (xin ? ixr : 0);
@@ -134,20 +151,20 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
                 const int iyr = 4 * ty + off + r;
                 const bool yin = (unsigned)iyr < (unsigned)v.H;
                 const int iy = reflect ? reflw(iyr, v.H) : (yin ? iyr : 0);
-                const float val = x[vaddr(v, b, iy, ix, C) + c];
-                d[r] = (reflect || (xin && yin)) ? val : 0.f;
+                const F val = *reinterpret_cast<const F*>(x + vaddr(v, b, iy, ix, C) + c);
+                d[r] = (reflect || (xin && yin)) ? val : (F)(0.f);
             }
-            float o[6];
+            F o[6];
             bt6(d, o);
 #pragma unroll
             for (int r = 0; r < 6; ++r) tmp[r][j] = o[r];
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {              // rows: (B^T d) B
-            float o[6];
+            F o[6];
             bt6(tmp[r], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) Vp[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<F*>(Vp + ((size_t)(r * 6 + j) * T + t) * C + c) = o[j];
         }
     }
 }
@@ -155,35 +172,39 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 // sum = 0: y through view ph  (+)= act((A^T M_ph A) + bias), one view per phase (forward: the phases interleave into the hi-res map);
 // sum = 1: y through view 0   (+)= sum over the nph phases of A^T M_ph A  (dgrad: all phases land on the same low-res dx).
 // Outputs beyond the view's logical extent (ragged last tiles) are dropped.
+template <int NV>
 __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y, int B, WViews vs,
-                                                          int C, int TY, int TX, int act, int accumulate, int sum) {
-    const int64_t T = (int64_t)B * TY * TX, n = T * C;
+                                                          int C, int TY, int TX, int act, int accumulate, int sum, float2* __restrict__ stats) {
+    typedef typename VecOf<NV>::T F;
+    const int Cv = C / NV;
+    const int64_t T = (int64_t)B * TY * TX, n = T * Cv;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int64_t t = i / C;
+        const int c = (int)(i % Cv) * NV;
+        const int64_t t = i / Cv;
         const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
-        const float bv = bias ? bias[c] : 0.f;
-        float tot[4][4];
+        const F bv = bias ? *reinterpret_cast<const F*>(bias + c) : (F)(0.f);
+        F tot[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tot[r][j] = 0.f;
+            for (int j = 0; j < 4; ++j) tot[r][j] = (F)(0.f);
+        F st_sh = (F)(0.f), st_s = (F)(0.f), st_q = (F)(0.f);      // normalisation statistics of this tile (stats != nullptr), shifted sums
         for (int ph = 0; ph < vs.nph; ++ph) {
             const float* Mp = M + (size_t)ph * 36 * T * C;
-            float tmp[4][6];
+            F tmp[4][6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {              // columns: A^T M
-                float m[6];
+                F m[6];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) m[r] = Mp[((size_t)(r * 6 + j) * T + t) * C + c];
-                float o[4];
+                for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const F*>(Mp + ((size_t)(r * 6 + j) * T + t) * C + c);
+                F o[4];
                 at4(m, o);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tmp[r][j] = o[r];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {              // rows: (A^T M) A
-                float o[4];
+                F o[4];
                 at4(tmp[r], o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -192,12 +213,26 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                         const WView v = vs.v[ph];
                         const int oy = 4 * ty + r, ox = 4 * tx + j;
                         if (oy < v.H && ox < v.W) {
-                            float* dst = y + vaddr(v, b, oy, ox, C) + c;
-                            const float val = actw(o[j] + bv, act);
+                            F* dst = reinterpret_cast<F*>(y + vaddr(v, b, oy, ox, C) + c);
+                            const F val = actv<NV>(o[j] + bv, act);
                             *dst = accumulate ? *dst + val : val;
+                            if (stats) {
+                                if (r == 0 && j == 0) st_sh = val;
+                                const F dv = val - st_sh;
+                                st_s += dv; st_q += dv * dv;
+                            }
                         }
                     }
                 }
+            }
+        }
+        if (stats) {      // part[b][tile][c] = (mean, M2) of the tile's 16 outputs: the chunk partials norm_finalize_* combines (elementwise.hip)
+            const F mean = st_sh + st_s * (1.f / 16.f), m2 = st_q - st_s * st_s * (1.f / 16.f);
+            float2* o = stats + (size_t)t * C + c;
+            if constexpr (NV == 1) o[0] = make_float2(mean, m2);
+            else {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) o[e] = make_float2(mean[e], m2[e]);
             }
         }
         if (sum) {
@@ -208,8 +243,8 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                 for (int j = 0; j < 4; ++j) {
                     const int oy = 4 * ty + r, ox = 4 * tx + j;
                     if (oy < v.H && ox < v.W) {
-                        float* dst = y + vaddr(v, b, oy, ox, C) + c;
-                        const float val = actw(tot[r][j] + bv, act);
+                        F* dst = reinterpret_cast<F*>(y + vaddr(v, b, oy, ox, C) + c);
+                        const F val = actv<NV>(tot[r][j] + bv, act);
                         *dst = accumulate ? *dst + val : val;
                     }
                 }
@@ -218,7 +253,8 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
 }
 
 // ---- weight gradient in the Winograd domain:  dU_f[co][ci] = sum_t dM_f[t][co] V_f[t][ci],  dM = A dY A^T,  dg = G^T dU G ----
-__device__ __forceinline__ void a6(const float (&y)[4], float (&m)[6]) {     // A y  (A = transpose of A^T, 6 x 4)
+template <typename F>
+__device__ __forceinline__ void a6(const F (&y)[4], F (&m)[6]) {     // A y  (A = transpose of A^T, 6 x 4)
     m[0] = y[0];
     m[1] = y[0] + y[1] + y[2] + y[3];
     m[2] = y[0] - y[1] + y[2] - y[3];
@@ -234,43 +270,46 @@ __device__ __forceinline__ void gt3(const float (&u)[6], float (&g)[3]) {    // 
 
 // dM[ph][f][t][c] = (A dY A^T)[f] of the 4x4 tile t of the output gradient seen through view ph (zero outside the view);
 // bpart[ph][j][c] (optional) = this thread's column sum of dy (bias gradient, reduced in order by wino_bias_finish_kernel).
-// Launch with gridDim.x * 256 a multiple of C: a thread keeps ONE channel.  blockIdx.y = phase.
+// Launch with gridDim.x * 256 a multiple of C / NV: a thread keeps ONE group of NV channels.  blockIdx.y = phase.
+template <int NV>
 __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ bpart, int B, WViews vs,
                                                            int C, int TY, int TX) {
+    typedef typename VecOf<NV>::T F;
     const WView v = vs.v[blockIdx.y];
+    const int Cv = C / NV;
     const int64_t T = (int64_t)B * TY * TX;
     float* dMp = dM + (size_t)blockIdx.y * 36 * T * C;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
-    const int c = (int)(gid % C);
-    float bs = 0.f;
-    for (int64_t t = gid / C; t < T; t += nth / C) {
+    const int c = (int)(gid % Cv) * NV;
+    F bs = (F)(0.f);
+    for (int64_t t = gid / Cv; t < T; t += nth / Cv) {
         const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
-        float tmp[6][4];
+        F tmp[6][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {              // columns: A dY
-            float q[4];
+            F q[4];
             const int ox = 4 * tx + j;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int oy = 4 * ty + r;
                 const bool in = oy < v.H && ox < v.W;
-                q[r] = in ? dy[vaddr(v, b, in ? oy : 0, in ? ox : 0, C) + c] : 0.f;
+                q[r] = in ? *reinterpret_cast<const F*>(dy + vaddr(v, b, in ? oy : 0, in ? ox : 0, C) + c) : (F)(0.f);
                 bs += q[r];
             }
-            float o[6];
+            F o[6];
             a6(q, o);
 #pragma unroll
             for (int r = 0; r < 6; ++r) tmp[r][j] = o[r];
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {              // rows: (A dY) A^T
-            float o[6];
+            F o[6];
             a6(tmp[r], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) dMp[((size_t)(r * 6 + j) * T + t) * C + c] = o[j];
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<F*>(dMp + ((size_t)(r * 6 + j) * T + t) * C + c) = o[j];
         }
     }
-    if (bpart) bpart[(size_t)blockIdx.y * nth + gid] = bs;     // [ph][gid / C][c]
+    if (bpart) *reinterpret_cast<F*>(bpart + ((size_t)blockIdx.y * (nth / Cv) + gid / Cv) * C + c) = bs;     // [ph][row = gid / Cv][c]
 }
 // db[c] += sum over the partial rows, in a fixed order: 16 channels x 16 row groups per workgroup, groups combined through LDS
 __global__ void __launch_bounds__(256) wino_bias_finish_kernel(const float* __restrict__ bpart, int rows, int C, float* __restrict__ db) {
@@ -338,7 +377,49 @@ bool wino_up5_enabled() {
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 int grid_for(int64_t n, int cap) { return (int)std::min<int64_t>(cdiv64(n, 256), cap); }
-const int WINO_BIAS_BLOCKS = 1024;       // x 256 threads: a multiple of every channel count in {64, 128, 256, 512}
+const int WINO_BIAS_BLOCKS = 1024;       // x 256 threads: a multiple of every channel-group count in {16 .. 256}
+const size_t WINO_BPART_BYTES = (size_t)WINO_BIAS_BLOCKS * 256 * 4 * sizeof(float);     // bias partial rows of one phase (4 channels per thread)
+
+// channels per thread of the transform kernels (ACLGAN_WINO_VEC = 1 | 2 | 4; 2 measured best, profiles/r02_experiments.md)
+int wino_vec() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_WINO_VEC"); v = e ? atoi(e) : 2; if (v != 1 && v != 2 && v != 4) v = 2; }
+    return v;
+}
+int launch_wino_input(const float* x, float* V, int B, const WViews& vs, int nph, int C, int TY, int TX, int off, int reflect, hipStream_t st) {
+    const int nv = wino_vec();
+    const dim3 grid(grid_for((int64_t)B * TY * TX * (C / nv), 16384), nph);
+    if (nv == 4) hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect);
+    else if (nv == 2) hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect);
+    else hipLaunchKernelGGL(wino_input_kernel<1>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect);
+    ACL_CHECK_LAUNCH("wino_input_kernel");
+    return ACLGAN_OK;
+}
+int launch_wino_output(const float* M, const float* bias, float* y, int B, const WViews& vs, int C, int TY, int TX, int act, int accumulate, int sum,
+                       hipStream_t st, float2* stats = nullptr) {
+    const int nv = wino_vec();
+    const dim3 grid(grid_for((int64_t)B * TY * TX * (C / nv), 16384));
+    if (nv == 4) hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, sum, stats);
+    else if (nv == 2) hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, sum, stats);
+    else hipLaunchKernelGGL(wino_output_kernel<1>, grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, sum, stats);
+    ACL_CHECK_LAUNCH("wino_output_kernel");
+    return ACLGAN_OK;
+}
+// returns the number of bias partial rows PER PHASE written to bpart ([ph][row][C]); C / nv must divide 256
+int launch_wino_outgrad(const float* dy, float* dM, float* bpart, int B, const WViews& vs, int nph, int C, int TY, int TX, hipStream_t st, int* rows) {
+    const int nv = wino_vec(), Cv = C / nv;
+    const int mult = std::max(1, Cv / 256);        // gridDim.x * 256 must be a multiple of Cv
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(WINO_BIAS_BLOCKS, cdiv64((int64_t)B * TY * TX * Cv, 256)));
+    blocks = cdiv(blocks, mult) * mult;
+    *rows = blocks * 256 / Cv;
+    const dim3 grid(blocks, nph);
+    if (nv == 4) hipLaunchKernelGGL(wino_outgrad_kernel<4>, grid, dim3(256), 0, st, dy, dM, bpart, B, vs, C, TY, TX);
+    else if (nv == 2) hipLaunchKernelGGL(wino_outgrad_kernel<2>, grid, dim3(256), 0, st, dy, dM, bpart, B, vs, C, TY, TX);
+    else hipLaunchKernelGGL(wino_outgrad_kernel<1>, grid, dim3(256), 0, st, dy, dM, bpart, B, vs, C, TY, TX);
+    ACL_CHECK_LAUNCH("wino_outgrad_kernel");
+    return ACLGAN_OK;
+}
+bool wino_bias_ok(int C) { const int Cv = C / wino_vec(); return C % wino_vec() == 0 && (256 % Cv == 0 || Cv % 256 == 0); }
 
 WViews one_view(const WView& v) { WViews w; w.v[0] = v; w.v[1] = v; w.v[2] = v; w.v[3] = v; w.nph = 1; return w; }
 
@@ -364,7 +445,7 @@ size_t conv_wino_scratch_bytes(const ConvGeom& g) {
 namespace {
 // filter transform -> input transform -> 36 GEMMs -> output transform.  `in` has Cin_ channels, `out` Cout_.
 int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* w, int w_co, int w_ci, int flip, const float* bias, float* out,
-             int act, int accumulate, int reflect, void* scratch, hipStream_t st) {
+             int act, int accumulate, int reflect, void* scratch, hipStream_t st, float2* stats = nullptr) {
     const int TY = H / 4, TX = W / 4;
     const int64_t T = (int64_t)B * TY * TX;
     char* cur = (char*)scratch;
@@ -374,18 +455,17 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
     const WViews vw = one_view(ident_view(H, W));
     hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip);
     ACL_CHECK_LAUNCH("wino_filter_kernel");
-    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * Cin_, 16384), 1), dim3(256), 0, st, in, V, B, vw, Cin_, TY, TX, -1, reflect);
-    ACL_CHECK_LAUNCH("wino_input_kernel");
-    const int rc = gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, 0, st);
+    int rc = launch_wino_input(in, V, B, vw, 1, Cin_, TY, TX, -1, reflect, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(T * Cout_, 16384)), dim3(256), 0, st, M, bias, out, B, vw, Cout_, TY, TX, act, accumulate, 0);
-    ACL_CHECK_LAUNCH("wino_output_kernel");
-    return ACLGAN_OK;
+    rc = gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, 0, st);
+    if (rc) return rc;
+    return launch_wino_output(M, bias, out, B, vw, Cout_, TY, TX, act, accumulate, 0, st, stats);
 }
 }  // namespace
-int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st) {
+// stats (optional): [B][Ho/4 * Wo/4][Co] (mean, M2) pairs of the 4x4 output tiles -- the normalisation layer's chunk partials, for free
+int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats) {
     if (!conv_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
-    return wino_run(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, w, g.Co, g.Ci, 0, bias, y, g.act, 0, 1, scratch, st);
+    return wino_run(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, w, g.Co, g.Ci, 0, bias, y, g.act, 0, 1, scratch, st, (float2*)stats);
 }
 // the INTERIOR of the padded-grid gradient (= dx without the mirrored halo contributions): dx (+)= dy (*) flipped w^T, zero padding
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st) {
@@ -398,26 +478,27 @@ size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
     return align256((size_t)36 * T * g.Ci * 4) + align256((size_t)36 * T * g.Co * 4) + align256((size_t)36 * g.Co * g.Ci * 4) +
-           align256((size_t)WINO_BIAS_BLOCKS * 256 * 4) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
+           align256(WINO_BPART_BYTES) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
 }
 int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
-    if ((WINO_BIAS_BLOCKS * 256) % g.Co != 0) return ACLGAN_EUNSUPPORTED;
+    if (!wino_bias_ok(g.Co)) return ACLGAN_EUNSUPPORTED;
     const int TY = g.Ho / 4, TX = g.Wo / 4;
     const int64_t T = (int64_t)g.B * TY * TX;
     char* cur = (char*)scratch;
     float* V = take(cur, (size_t)36 * T * g.Ci * 4);
     float* dM = take(cur, (size_t)36 * T * g.Co * 4);
     float* dU = take(cur, (size_t)36 * g.Co * g.Ci * 4);
-    float* bpart = take(cur, (size_t)WINO_BIAS_BLOCKS * 256 * 4);
+    float* bpart = take(cur, WINO_BPART_BYTES);
     void* part = cur;
     const WViews vw = one_view(ident_view(g.Hi, g.Wi));
-    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(T * g.Ci, 16384), 1), dim3(256), 0, st, x, V, g.B, vw, g.Ci, TY, TX, -1, 1);
-    ACL_CHECK_LAUNCH("wino_input_kernel");
-    hipLaunchKernelGGL(wino_outgrad_kernel, dim3(WINO_BIAS_BLOCKS, 1), dim3(256), 0, st, dy, dM, db ? bpart : (float*)nullptr, g.B, vw, g.Co, TY, TX);
-    ACL_CHECK_LAUNCH("wino_outgrad_kernel");
+    int rc0 = launch_wino_input(x, V, g.B, vw, 1, g.Ci, TY, TX, -1, 1, st);
+    if (rc0) return rc0;
+    int brows = 0;
+    rc0 = launch_wino_outgrad(dy, dM, db ? bpart : (float*)nullptr, g.B, vw, 1, g.Co, TY, TX, st, &brows);
+    if (rc0) return rc0;
     if (db) {
-        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, WINO_BIAS_BLOCKS * 256 / g.Co, g.Co, db);
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, brows, g.Co, db);
         ACL_CHECK_LAUNCH("wino_bias_finish_kernel");
     }
     hipError_t e = hipMemsetAsync(dU, 0, (size_t)36 * g.Co * g.Ci * sizeof(float), st);
@@ -466,13 +547,11 @@ int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp,
     float* M = take(cur, (size_t)144 * q.T * g.Co * 4);
     hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0);
     ACL_CHECK_LAUNCH("wino_filter_kernel(up5)");
-    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(q.T * g.Ci, 16384), 1), dim3(256), 0, st, x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), g.Ci, q.TY, q.TX, 0, 0);
-    ACL_CHECK_LAUNCH("wino_input_kernel(up5)");
-    const int rc = gemm_slices_f32(V, U, M, (int)q.T, g.Ci, g.Co, 144, 36, st);      // the 4 phases share V: A offset = (f % 36) planes
+    int rc = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(q.T * g.Co, 16384)), dim3(256), 0, st, M, bias, y, g.B, q.ph, g.Co, q.TY, q.TX, g.act, 0, 0);
-    ACL_CHECK_LAUNCH("wino_output_kernel(up5)");
-    return ACLGAN_OK;
+    rc = gemm_slices_f32(V, U, M, (int)q.T, g.Ci, g.Co, 144, 36, st);      // the 4 phases share V: A offset = (f % 36) planes
+    if (rc) return rc;
+    return launch_wino_output(M, bias, y, g.B, q.ph, g.Co, q.TY, q.TX, g.act, 0, 0, st);
 }
 // dgrad: U' [4][36][Ci][Co] | V' [4][36][Td][Co] | M [4][36][Td][Ci];  dx (+)= sum over phases (full correlation with the flipped filter)
 size_t conv_up5_wino_dgrad_scratch_bytes(const ConvGeom& g) {
@@ -490,39 +569,37 @@ int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* 
     hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1);
     ACL_CHECK_LAUNCH("wino_filter_kernel(up5 dgrad)");
     // dx[u] = sum_k wflip[k] dy_phase[u - 2 + k]: patches start 2 before the tile, zero outside the 62 x 62 phase view
-    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(q.Td * g.Co, 16384), 4), dim3(256), 0, st, dy, V, g.B, q.ph, g.Co, q.TYd, q.TXd, -2, 0);
-    ACL_CHECK_LAUNCH("wino_input_kernel(up5 dgrad)");
-    const int rc = gemm_slices_f32(V, U, M, (int)q.Td, g.Co, g.Ci, 144, 0, st);
+    int rc = launch_wino_input(dy, V, g.B, q.ph, 4, g.Co, q.TYd, q.TXd, -2, 0, st);
+    if (rc) return rc;
+    rc = gemm_slices_f32(V, U, M, (int)q.Td, g.Co, g.Ci, 144, 0, st);
     if (rc) return rc;
     WViews dst = one_view(ident_view(g.Hi, g.Wi));
     dst.nph = 4;
-    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(q.Td * g.Ci, 16384)), dim3(256), 0, st, M, (const float*)nullptr, dx, g.B, dst, g.Ci, q.TYd, q.TXd,
-                       ACLGAN_ACT_NONE, accumulate, 1);
-    ACL_CHECK_LAUNCH("wino_output_kernel(up5 dgrad)");
-    return ACLGAN_OK;
+    return launch_wino_output(M, nullptr, dx, g.B, dst, g.Ci, q.TYd, q.TXd, ACLGAN_ACT_NONE, accumulate, 1, st);
 }
 // wgrad: V [36][T][Ci] | dM [4][36][T][Co] | dU [4][36][Co][Ci] | bias partials [4][...] | GEMM partial tiles;  dwp[phase] += G^T dU G
 size_t conv_up5_wino_wgrad_scratch_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     const Up5Geo q = up5_geo(g);
     return align256((size_t)36 * q.T * g.Ci * 4) + align256((size_t)144 * q.T * g.Co * 4) + align256((size_t)144 * g.Co * g.Ci * 4) +
-           align256((size_t)4 * WINO_BIAS_BLOCKS * 256 * 4) + gemm_at_b_slices_scratch((int)q.T, g.Co, g.Ci, 144) + 256;
+           align256(4 * WINO_BPART_BYTES) + gemm_at_b_slices_scratch((int)q.T, g.Co, g.Ci, 144) + 256;
 }
 int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st) {
-    if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || (WINO_BIAS_BLOCKS * 256) % g.Co != 0) return ACLGAN_EUNSUPPORTED;
+    if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !wino_bias_ok(g.Co)) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
     float* V = take(cur, (size_t)36 * q.T * g.Ci * 4);
     float* dM = take(cur, (size_t)144 * q.T * g.Co * 4);
     float* dU = take(cur, (size_t)144 * g.Co * g.Ci * 4);
-    float* bpart = take(cur, (size_t)4 * WINO_BIAS_BLOCKS * 256 * 4);
+    float* bpart = take(cur, 4 * WINO_BPART_BYTES);
     void* part = cur;
-    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(q.T * g.Ci, 16384), 1), dim3(256), 0, st, x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), g.Ci, q.TY, q.TX, 0, 0);
-    ACL_CHECK_LAUNCH("wino_input_kernel(up5 wgrad)");
-    hipLaunchKernelGGL(wino_outgrad_kernel, dim3(WINO_BIAS_BLOCKS, 4), dim3(256), 0, st, dy, dM, db ? bpart : (float*)nullptr, g.B, q.ph, g.Co, q.TY, q.TX);
-    ACL_CHECK_LAUNCH("wino_outgrad_kernel(up5)");
+    int rc0 = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
+    if (rc0) return rc0;
+    int brows = 0;
+    rc0 = launch_wino_outgrad(dy, dM, db ? bpart : (float*)nullptr, g.B, q.ph, 4, g.Co, q.TY, q.TX, st, &brows);
+    if (rc0) return rc0;
     if (db) {      // interior pixels (the four phases); the ring launch of the caller adds the ring pixels
-        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, 4 * WINO_BIAS_BLOCKS * 256 / g.Co, g.Co, db);
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, 4 * brows, g.Co, db);
         ACL_CHECK_LAUNCH("wino_bias_finish_kernel(up5)");
     }
     hipError_t e = hipMemsetAsync(dU, 0, (size_t)144 * g.Co * g.Ci * sizeof(float), st);

@@ -218,17 +218,23 @@ size_t norm_scratch_bytes(int B, int HW, int C) {
     return (size_t)B * nchunks * C * sizeof(float2) + (size_t)B * C * 5 * sizeof(float) + 256;
 }
 
+// stats != nullptr: the producer of x already wrote the chunk partials [B][HW / stats_chunk][C] (mean, M2) -- conv_fwd's epilogue
+// (conv_fwd_stats_chunk) -- and the statistics pass over x is skipped
 int norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const float* w, const float* b, int w_stride,
-             const float* residual, float* y, float* mean, float* rstd, void* scratch, hipStream_t st) {
+             const float* residual, float* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats, int stats_chunk) {
     ACL_REQUIRE(pow2(C) && C >= 4 && C <= 1024, "norm: C=%d must be a power of two in [4,1024]", C);
     ACL_REQUIRE(kind == ACLGAN_NORM_IN || kind == ACLGAN_NORM_ADAIN || kind == ACLGAN_NORM_LN, "norm: bad kind %d", kind);
     ACL_REQUIRE(!(residual && act != ACLGAN_ACT_NONE), "norm: residual requires act none");
-    const int chunk = norm_chunk_pixels(B, HW), nchunks = cdiv(HW, chunk);
-    float2* part = (float2*)scratch;
-    float* scale = (float*)(part + (size_t)B * nchunks * C);
+    ACL_REQUIRE(!stats || (stats_chunk > 0 && HW % stats_chunk == 0), "norm: bad statistics chunk %d for %d pixels", stats_chunk, HW);
+    const int own_chunk = norm_chunk_pixels(B, HW);
+    const int chunk = stats ? stats_chunk : own_chunk, nchunks = cdiv(HW, chunk);
+    float2* part = stats ? (float2*)stats : (float2*)scratch;
+    float* scale = (float*)((float2*)scratch + (size_t)B * cdiv(HW, own_chunk) * C);
     float* shift = scale + (size_t)B * C;
-    hipLaunchKernelGGL(norm_stats_kernel, dim3(nchunks, B), dim3(256), 0, st, x, part, HW, C, chunk, nchunks);
-    ACL_CHECK_LAUNCH("norm_stats_kernel");
+    if (!stats) {
+        hipLaunchKernelGGL(norm_stats_kernel, dim3(nchunks, B), dim3(256), 0, st, x, part, HW, C, chunk, nchunks);
+        ACL_CHECK_LAUNCH("norm_stats_kernel");
+    }
     if (kind == ACLGAN_NORM_LN) {
         ACL_REQUIRE(w && b, "LN needs gamma/beta");
         hipLaunchKernelGGL(norm_finalize_ln_kernel, dim3(B), dim3(256), 0, st, part, C, HW, chunk, nchunks, w, b, mean, rstd, scale, shift);

@@ -287,15 +287,6 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     const int dt = c.dtype;
     const bool h16 = dt != ACLGAN_DTYPE_FP32 && W.w16 != nullptr;
     const bool f16 = h16 && conv16_eligible(g, 0), d16 = h16 && conv16_eligible(g, 1), w16 = h16 && conv16_eligible(g, 2);
-    {
-        const size_t mark = c.top;
-        void* fscr = nullptr;
-        const size_t fb = f16 ? conv_fwd16_scratch_bytes(g) : conv_fwd_scratch_bytes(g);   // merged phase weights (upsample + 5x5 layers), split-K partials
-        if (fb) { fscr = c.alloc(fb); NEED(fscr); }
-        if (f16) RUN(conv_fwd16(g, dt, in->d, W.w, W.w16, W.b, co->d, fscr, c.st));
-        else RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr));
-        c.top = mark;
-    }
     Act* out = co;
     float *mean = nullptr, *rstd = nullptr;
     const int HW = g.Ho * g.Wo;
@@ -305,12 +296,27 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         const int nstat = ns.kind == ACLGAN_NORM_LN ? g.B : g.B * Co;
         mean = c.allocf(nstat); rstd = c.allocf(nstat);
         NEED(mean); NEED(rstd);
-        const size_t mark = c.top;
+    }
+    const size_t mark = c.top;
+    // normalisation statistics from the conv epilogue where the forward kernel offers them (Winograd output transform)
+    const int schunk = (ns.kind != ACLGAN_NORM_NONE && !f16) ? conv_fwd_stats_chunk(g) : 0;
+    float* stats = nullptr;
+    if (schunk) { stats = c.allocf((size_t)2 * g.B * (HW / schunk) * Co); NEED(stats); }
+    {
+        const size_t fmark = c.top;
+        void* fscr = nullptr;
+        const size_t fb = f16 ? conv_fwd16_scratch_bytes(g) : conv_fwd_scratch_bytes(g);   // merged phase weights (upsample + 5x5 layers), split-K partials
+        if (fb) { fscr = c.alloc(fb); NEED(fscr); }
+        if (f16) RUN(conv_fwd16(g, dt, in->d, W.w, W.w16, W.b, co->d, fscr, c.st));
+        else RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr, stats));
+        c.top = fmark;
+    }
+    if (ns.kind != ACLGAN_NORM_NONE) {
         void* scr = c.alloc(norm_scratch_bytes(g.B, HW, Co));
         NEED(scr);
-        RUN(norm_fwd(ns.kind, act, g.B, HW, Co, co->d, ns.w, ns.b, ns.w_stride, residual ? residual->d : nullptr, out->d, mean, rstd, scr, c.st));
-        c.top = mark;
+        RUN(norm_fwd(ns.kind, act, g.B, HW, Co, co->d, ns.w, ns.b, ns.w_stride, residual ? residual->d : nullptr, out->d, mean, rstd, scr, c.st, stats, schunk));
     }
+    c.top = mark;
     *out_p = out;
     if (!want_grad) return ACLGAN_OK;
     aclgan_ctx* cp = &c;

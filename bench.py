@@ -60,12 +60,18 @@ RESBLOCK_GMAC_256 = 637.8     # of which the 3x3 ResBlock convs: 120 forward + 7
 def flops_per_image(S, dtype="fp32"):
     """(contract, executed) TFLOP per image of one dis+gen step at SxS.  Executed = what the kernels really issue: inside the
     border ring the sub-pixel decomposition runs 9/25 of the upsample+5x5 MACs, and (fp32 only) the Winograd F(4x4,3x3) path runs
-    the 3x3 ResBlock convolutions -- forward, dgrad interior, wgrad -- with 36/144 of theirs."""
+    the 3x3 ResBlock convolutions -- forward, dgrad interior, wgrad -- and the four VALID 3x3 phases of the sub-pixel layers with
+    36/144 of theirs (times the ragged-tile overhead of the (h-2) x (h-2) phase views)."""
     scale = (S / 256.0) ** 2
     interior = 0.5 * (((S // 2 - 4) / (S // 2)) ** 2 + ((S - 4) / S) ** 2)
-    executed_gmac = 1311.6 - UPCONV_GMAC_256 * (16.0 / 25.0) * interior
-    if dtype == "fp32" and S % 16 == 0 and os.environ.get("ACLGAN_NOWINO", "0") in ("", "0"):
+    wino = dtype == "fp32" and S % 16 == 0 and os.environ.get("ACLGAN_NOWINO", "0") in ("", "0")
+    phase_gmac = UPCONV_GMAC_256 * (9.0 / 25.0) * interior
+    executed_gmac = 1311.6 - UPCONV_GMAC_256 * interior + phase_gmac
+    if wino:
         executed_gmac -= RESBLOCK_GMAC_256 * 0.75
+        if os.environ.get("ACLGAN_NOWINOUP5", "0") in ("", "0"):
+            ragged = 0.5 * sum((4.0 * -(-(h - 2) // 4) / (h - 2)) ** 2 for h in (S // 4, S // 2))
+            executed_gmac -= phase_gmac * (1.0 - 0.25 * ragged)
     return TFLOP_PER_IMAGE_256 * scale, 2e-3 * executed_gmac * scale
 
 

@@ -263,6 +263,17 @@ int aclgan_conv2d_fwd_naive(const aclgan_conv_desc* d, const float* x, const flo
 int aclgan_norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const float* w,
                     const float* b, int w_stride, const float* residual, float* y, float* mean,
                     float* rstd, void* scratch, void* stream);
+/* Conv2dBlock.forward (networks.py:365-371): conv (desc.act must be none) + norm + activation (+ residual), as the step runs it.
+ * y_conv receives the convolution output (kept for the backward), y the block output.  Where the forward kernel holds whole
+ * output tiles (the Winograd output transform of the 3x3 ResBlock convolutions) the normalisation statistics are emitted from
+ * the conv epilogue and the separate statistics pass over y_conv is skipped; *stats_fused (optional) reports which happened.
+ * Same result as aclgan_conv2d_fwd_ws followed by aclgan_norm_fwd up to fp32 summation order of the statistics.
+ * scratch: aclgan_conv2d_block_fwd_scratch_bytes(d) bytes. */
+int aclgan_conv2d_block_fwd(const aclgan_conv_desc* d, int norm_kind, int act, const float* x, const float* w,
+                            const float* bias, const float* nw, const float* nb, int n_stride, const float* residual,
+                            float* y_conv, float* y, float* mean, float* rstd, void* scratch, int* stats_fused,
+                            void* stream);
+size_t aclgan_conv2d_block_fwd_scratch_bytes(const aclgan_conv_desc* d);
 /* backward: given dy (grad of y) computes dx (grad of x), and ACCUMULATES dw/db ([B][C] for ADAIN
  * with row stride w_stride, [C] for LN; ignored for IN) and, if dres != NULL, dres (+)= the
  * activation-masked dy (the residual branch).  dres_accumulate selects += vs =. */

@@ -252,6 +252,62 @@ def test_norm_fwd_bwd(L, case):
         assert rel_err(dbg, b.grad) < 5 * TOL
 
 
+# Conv2dBlock.forward as one operator (networks.py:365-371): (B, H, W, Ci, Co, k, norm, act, residual, statistics from the conv epilogue?)
+BLOCK_CASES = [
+    (2, 16, 16, 256, 256, 3, "in", "relu", False, True),      # ResBlock conv 1: Winograd output transform emits the IN statistics
+    (2, 8, 12, 256, 256, 3, "in", "none", True, True),        # ResBlock conv 2 (+ residual), non-square map
+    (3, 8, 8, 64, 128, 3, "adain", "relu", False, True),      # decoder ResBlock (AdaIN), Cin != Cout
+    (1, 64, 64, 64, 64, 3, "ln", "relu", False, True),        # LN over the tile partials (256 tiles x 64 channels)
+    (2, 10, 12, 64, 64, 3, "in", "relu", False, False),       # H % 4 != 0: direct kernel, separate statistics pass
+    (2, 16, 16, 64, 128, 4, "in", "relu", False, False),      # strided encoder conv: separate statistics pass
+]
+
+
+@pytest.mark.parametrize("case", BLOCK_CASES)
+def test_conv_block_fwd(L, case):
+    from gpu_util import conv_desc, nhwc, nchw, ohwi, rel_err
+    B, H, W, Ci, Co, k, kind, act, use_res, expect_fused = case
+    s, p = (2, 1) if k == 4 else (1, 1)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (2.0 / (Ci * k * k)) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    yc_ref = O.conv_block(x, w, b, s, p, "none")
+    res = torch.randn(yc_ref.shape, generator=g) if use_res else None
+    if kind == "adain":
+        nw, nb = torch.rand(B, Co, generator=g) + 0.5, torch.randn(B, Co, generator=g) * 0.2
+    elif kind == "ln":
+        nw, nb = torch.rand(Co, generator=g), torch.randn(Co, generator=g) * 0.1
+    else:
+        nw = nb = None
+    y_ref = _norm_ref(kind, act, yc_ref, nw, nb, res)
+
+    d = conv_desc(L, B, H, W, Ci, Co, k, s, p, 0, "none")
+    xg, wg, bg = nhwc(x).cuda(), ohwi(w).cuda(), b.cuda()
+    nwg = nw.cuda() if nw is not None else None
+    nbg = nb.cuda() if nb is not None else None
+    resg = nhwc(res).cuda() if use_res else None
+    Ho, Wo = yc_ref.shape[2], yc_ref.shape[3]
+    yc = torch.empty(B, Ho, Wo, Co, device="cuda"); y = torch.empty_like(yc)
+    nstat = B if kind == "ln" else B * Co
+    mean = torch.empty(nstat, device="cuda"); rstd = torch.empty(nstat, device="cuda")
+    scratch = torch.empty(L.lib.aclgan_conv2d_block_fwd_scratch_bytes(C.byref(d)) // 4 + 64, device="cuda")
+    fused = C.c_int(-1)
+    L.check(L.lib.aclgan_conv2d_block_fwd(C.byref(d), L.NORM[kind], L.ACT[act], L.ptr(xg), L.ptr(wg), L.ptr(bg), L.ptr(nwg), L.ptr(nbg),
+                                          Co if kind == "adain" else 0, L.ptr(resg), L.ptr(yc), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                          L.ptr(scratch), C.byref(fused), L.stream_ptr()), "conv2d_block_fwd")
+    assert fused.value == int(expect_fused)
+    assert rel_err(nchw(yc), yc_ref) < TOL
+    assert rel_err(nchw(y), y_ref) < TOL
+    # the statistics the block saved for the backward = those of the separate normalisation operator on the same conv output
+    y2 = torch.empty_like(y); mean2 = torch.empty_like(mean); rstd2 = torch.empty_like(rstd)
+    nscr = torch.empty(L.lib.aclgan_norm_scratch_bytes(B, Ho * Wo, Co) // 4 + 16, device="cuda")
+    L.check(L.lib.aclgan_norm_fwd(L.NORM[kind], L.ACT[act], B, Ho * Wo, Co, L.ptr(yc), L.ptr(nwg), L.ptr(nbg), Co if kind == "adain" else 0,
+                                  L.ptr(resg), L.ptr(y2), L.ptr(mean2), L.ptr(rstd2), L.ptr(nscr), L.stream_ptr()), "norm_fwd")
+    assert rel_err(mean, mean2) < 1e-5 and rel_err(rstd, rstd2) < 1e-5
+    assert rel_err(y, y2) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 6, 64, 64), (1, 3, 7, 9), (3, 3, 32, 32), (2, 6, 2, 2)])
 def test_avgpool(L, shape):
     from gpu_util import nhwc, nchw, rel_err

@@ -181,15 +181,21 @@ def test_update_steps_match_reference(T, fix, ltol, gtol):
 
     # parameters after Adam: every element moved by at most ~lr on step 1, and the well-conditioned
     # ones agree with the reference's post-step statistics
+    # Step 1 of Adam moves every element by ~lr * sign(g): an element whose gradient is within fp32 summation noise of zero may go
+    # the other way (2 * lr off), which shifts the tensor norm by up to 2 * lr * |p_i| / ||p||.  The norm bound allows two such
+    # elements of the largest magnitude on top of 1e-5 relative (seen: one element of a 64-entry LayerNorm beta, 1.8e-5).
+    def norm_tol(nrm, mx):
+        return 1e-5 * max(1.0, nrm) + 2 * (2 * cfg["lr"] * mx / max(nrm, 1e-12))
+
     for key, (s, nrm, mx) in meta["param_stats_after_gen"].items():
         net, k = key.split("/", 1)
         p = dict(getattr(trg, net).named_parameters())[k]
-        assert abs(float(p.double().norm()) - nrm) <= 1e-5 * max(1.0, nrm), key
+        assert abs(float(p.double().norm()) - nrm) <= norm_tol(nrm, mx), key
         assert (p.cpu() - nets[net][k]).abs().max().item() <= 1.01 * cfg["lr"] + 1e-9, key
     for key, (s, nrm, mx) in meta["param_stats_after_dis"].items():
         net, k = key.split("/", 1)
         p = dict(getattr(trd, net).named_parameters())[k]
-        assert abs(float(p.double().norm()) - nrm) <= 1e-5 * max(1.0, nrm), key
+        assert abs(float(p.double().norm()) - nrm) <= norm_tol(nrm, mx), key
 
 
 def test_chained_steps_and_lr_schedule(T):
