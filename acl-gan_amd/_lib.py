@@ -69,6 +69,8 @@ SYNC_FN = C.CFUNCTYPE(None, vp, vp, ci)
 # every symbol include/aclgan_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "aclgan_version": (ci, []),
+    "aclgan_set_deterministic": (ci, [ci]),
+    "aclgan_get_deterministic": (ci, []),
     "aclgan_last_error": (C.c_char_p, []),
     "aclgan_ctx_create": (ci, [C.POINTER(Arch), C.POINTER(vp)]),
     "aclgan_ctx_destroy": (None, [vp]),

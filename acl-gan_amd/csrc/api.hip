@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace aclgan {
 
@@ -19,13 +20,23 @@ int hip_fail(hipError_t e, const char* what) {
     return ACLGAN_EHIP;
 }
 
+static int g_determ = -1;
+bool deterministic() {
+    if (g_determ < 0) { const char* e = getenv("ACLGAN_DETERMINISTIC"); g_determ = (e && atoi(e)) ? 1 : 0; }
+    return g_determ == 1;
+}
+void set_deterministic(int on) { g_determ = on ? 1 : 0; }
+
 }  // namespace aclgan
 
 using namespace aclgan;
 
 #include <algorithm>
+
 extern "C" {
 
+int aclgan_set_deterministic(int on) { set_deterministic(on); return ACLGAN_OK; }
+int aclgan_get_deterministic(void) { return deterministic() ? 1 : 0; }
 int aclgan_version(void) { return 200; }   // 0.2.0: 16-bit MFMA path, gradient buckets
 const char* aclgan_last_error(void) { return g_err; }
 

@@ -22,6 +22,18 @@ int hip_fail(hipError_t e, const char* what);
         if (!(cond)) { ::aclgan::set_error(__VA_ARGS__); return ACLGAN_EINVAL; } \
     } while (0)
 
+// Deterministic mode (aclgan_set_deterministic / ACLGAN_DETERMINISTIC=1): every reduction that the default plan combines with fp32
+// atomics (reflection halo and small-grid split-K of dgrad, the thin / odd-channel weight gradients, bias column sums, LayerNorm
+// parameter gradients, the L1 loss value) takes an ordered path instead -- gradients and losses are reproducible bit for bit run to
+// run, at a few % of step time.  Scratch sizes depend on the mode: set it before sizing workspaces.
+bool deterministic();
+void set_deterministic(int on);
+// out[i] += part[0][i] + part[1][i] + ... (slices added in index order); part is [nslices][n]
+int reduce_slices_ordered(const float* part, int64_t n, int nslices, float* out, hipStream_t st);
+// db[c] += sum over the M rows of dy[M][C], reproducible: row chunks -> part [chunks][C] -> ordered.  part: colsum_ordered_bytes(M, C)
+size_t colsum_ordered_bytes(int64_t M, int C);
+int colsum_ordered(const float* dy, float* db, int64_t M, int C, void* part, hipStream_t st);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -37,6 +49,8 @@ struct ConvGeom {
 int make_geom(const aclgan_conv_desc* d, ConvGeom* g);
 
 // ---- kernel launchers (all async on `st`) ----
+int conv_fold(const ConvGeom& g, const float* dxp, float* dx, int accumulate, hipStream_t st);
+bool conv_wgrad_fast_supported(const ConvGeom& g);
 // scratch (optional, conv_fwd_scratch_bytes): enables the sub-pixel path of the upsample+5x5 decoder convs
 int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr);
 // > 0: conv_fwd (with scratch) can emit the normalisation statistics of its output from its epilogue: stats[B][Ho*Wo / chunk][Co] =
@@ -141,7 +155,9 @@ int focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg,
 // lscale (optional, device): fp16 dynamic loss scale; the gradient seed is multiplied by lscale[0], the reported loss is not
 int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st, const float* lscale = nullptr);
 // L1 (trainer.py:61-62): loss_slot = mean|a[..,:3] - b|; a has a_stride channels (4: decoder output), b 3 channels.
-int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st, const float* lscale = nullptr);
+const int L1_PART_FLOATS = 1024;
+int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st,
+            const float* lscale = nullptr, float* part = nullptr);
 // focus losses (trainer.py:146-158).  focus_sums: per-workgroup partials part[2*blk] = sum(m - upper), part[2*blk+1] =
 // sum 1/(|m-.5|+eps) over the mask channel (ch3 of dec4); part holds 2*focus_sums_blocks(npix) floats
 int focus_sums_blocks(int64_t npix);

@@ -508,12 +508,28 @@ static int launch_dgrad(const ConvGeom& g, DgP p, hipStream_t st) {
     return ACLGAN_OK;
 }
 
+// padded-grid gradient -> dx: reflection_pad2d backward (+ upsample_nearest2d backward); a gather, no atomics
+int conv_fold(const ConvGeom& g, const float* dxp, float* dx, int accumulate, hipStream_t st) {
+    FoldP f;
+    f.dxp = dxp; f.dx = dx; f.B = g.B; f.Hi = g.Hi; f.Wi = g.Wi; f.Ci = g.Ci; f.Hu = g.Hu; f.Wu = g.Wu;
+    f.Hp = g.Hp; f.Wp = g.Wp; f.p = g.p; f.up = g.up; f.accumulate = accumulate;
+    if (g.Ci % 4 == 0) {
+        f.total = (int64_t)g.B * g.Hi * g.Wi * (g.Ci / 4);
+        hipLaunchKernelGGL(conv_fold_kernel<4>, dim3((unsigned)cdiv64(f.total, 256)), dim3(256), 0, st, f);
+    } else {
+        f.total = (int64_t)g.B * g.Hi * g.Wi * g.Ci;
+        hipLaunchKernelGGL(conv_fold_kernel<1>, dim3((unsigned)cdiv64(f.total, 256)), dim3(256), 0, st, f);
+    }
+    ACL_CHECK_LAUNCH("conv_fold_kernel");
+    return ACLGAN_OK;
+}
+
 int conv_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, void* scratch, int accumulate, hipStream_t st) {
     DgP p;
     p.dy = dy; p.w = w; p.dxp = (float*)scratch;
     p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.Ci = g.Ci; p.k = g.k; p.s = g.s; p.Hp = g.Hp; p.Wp = g.Wp;
     p.Hc = cdiv(g.Hp, g.s); p.Wc = cdiv(g.Wp, g.s); p.Mc = g.B * p.Hc * p.Wc; p.tiles_n = 0; p.nwg = 0;
-    {
+    if (!deterministic()) {     // (deterministic mode: the padded-grid path below -- one writer per element, then the fold gather)
         const int rc0 = conv_up5_dgrad(g, dy, w, dx, accumulate, scratch, st);
         if (rc0 != ACLGAN_EUNSUPPORTED) return rc0;
     }
@@ -527,18 +543,7 @@ int conv_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, vo
         else rc = launch_dgrad<4, 1, 2, 1>(g, p, st);
     }
     if (rc) return rc;
-    FoldP f;
-    f.dxp = (const float*)scratch; f.dx = dx; f.B = g.B; f.Hi = g.Hi; f.Wi = g.Wi; f.Ci = g.Ci; f.Hu = g.Hu; f.Wu = g.Wu;
-    f.Hp = g.Hp; f.Wp = g.Wp; f.p = g.p; f.up = g.up; f.accumulate = accumulate;
-    if (g.Ci % 4 == 0) {
-        f.total = (int64_t)g.B * g.Hi * g.Wi * (g.Ci / 4);
-        hipLaunchKernelGGL(conv_fold_kernel<4>, dim3((unsigned)cdiv64(f.total, 256)), dim3(256), 0, st, f);
-    } else {
-        f.total = (int64_t)g.B * g.Hi * g.Wi * g.Ci;
-        hipLaunchKernelGGL(conv_fold_kernel<1>, dim3((unsigned)cdiv64(f.total, 256)), dim3(256), 0, st, f);
-    }
-    ACL_CHECK_LAUNCH("conv_fold_kernel");
-    return ACLGAN_OK;
+    return conv_fold(g, (const float*)scratch, dx, accumulate, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -548,6 +553,7 @@ int conv_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, vo
 struct WgP {
     const float* x; const float* dy; float* dw;
     int Hi, Wi, Ci, Ho, Wo, Co, k, s, p, up, Hu, Wu, P, Kn, chunk, tiles_n, nwg;
+    long long zs = 0;     // deterministic mode: pixel slice z accumulates into its own zeroed copy dw + z*zs (added in order afterwards)
 };
 
 template <int WM, int WN, int TM, int TN, int VA, int VB>
@@ -660,7 +666,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_kernel(WgP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.Co) atomicAdd(p.dw + (size_t)m * p.Kn + n, acc[i][j][r]);
+                if (m < p.Co) atomicAdd(p.dw + (size_t)blockIdx.z * p.zs + (size_t)m * p.Kn + n, acc[i][j][r]);
             }
         }
     }
@@ -703,17 +709,28 @@ __global__ void __launch_bounds__(256) colsum_vec4_kernel(const float* __restric
     }
 }
 
+// split K so that the grid holds ~3 workgroups per CU, each split >= 256 pixels
+static void wgrad_generic_plan(int nwg, int P, int* splits, int* chunk) {
+    int sp = cdiv(768, nwg);
+    sp = std::max(1, std::min(sp, cdiv(P, 256)));
+    *chunk = cdiv(cdiv(P, sp), 16) * 16;
+    *splits = cdiv(P, *chunk);
+}
 template <int WM, int WN, int TM, int TN>
-static int launch_wgrad(const ConvGeom& g, WgP p, hipStream_t st) {
+static int launch_wgrad(const ConvGeom& g, WgP p, hipStream_t st, void* det_part) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles_m = cdiv(g.Co, BM);
     p.tiles_n = cdiv(p.Kn, BN);
     p.nwg = tiles_m * p.tiles_n;
-    // split K so that the grid holds ~3 workgroups per CU, each split >= 256 pixels
-    int splits = cdiv(768, p.nwg);
-    splits = max(1, min(splits, cdiv(p.P, 256)));
-    p.chunk = cdiv(cdiv(p.P, splits), 16) * 16;
-    splits = cdiv(p.P, p.chunk);
+    int splits;
+    wgrad_generic_plan(p.nwg, p.P, &splits, &p.chunk);
+    float* dw_out = p.dw;
+    const int64_t ndw = (int64_t)g.Co * p.Kn;
+    if (det_part != nullptr && splits > 1) {      // deterministic mode: one zeroed copy of dw per pixel slice, added in order below
+        hipError_t e = hipMemsetAsync(det_part, 0, (size_t)splits * ndw * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "memset wgrad slices");
+        p.dw = (float*)det_part; p.zs = ndw;
+    }
     dim3 grid(p.nwg, 1, splits), block(WM * WN * 64);
     const bool va = g.Co % 4 == 0, vb = g.Ci % 4 == 0;
     if (va && vb) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 4, 4>), grid, block, 0, st, p);
@@ -721,10 +738,20 @@ static int launch_wgrad(const ConvGeom& g, WgP p, hipStream_t st) {
     else if (vb) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 1, 4>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, 1, 1>), grid, block, 0, st, p);
     ACL_CHECK_LAUNCH("conv_wgrad_kernel");
+    if (p.zs) return reduce_slices_ordered(p.dw, ndw, splits, dw_out, st);
     return ACLGAN_OK;
 }
+// deterministic mode: slice copies of the general kernel (smallest tiles = most slices) + the ordered bias column sums
+static size_t wgrad_generic_det_bytes(const ConvGeom& g) {
+    int splits, chunk;
+    wgrad_generic_plan(1, g.M, &splits, &chunk);
+    return (((size_t)(splits + 1) * g.Co * g.K * sizeof(float) + 255) & ~(size_t)255) + colsum_ordered_bytes(g.M, g.Co);
+}
 
-size_t conv_wgrad_scratch_bytes(const ConvGeom& g) { return std::max(conv_wgrad_fast_scratch_bytes(g), conv_wgrad_small_scratch_bytes(g)); }
+size_t conv_wgrad_scratch_bytes(const ConvGeom& g) {
+    const size_t b = std::max(conv_wgrad_fast_scratch_bytes(g), conv_wgrad_small_scratch_bytes(g));
+    return (deterministic() && !conv_wgrad_fast_supported(g)) ? std::max(b, wgrad_generic_det_bytes(g)) : b;    // general kernel: slice copies
+}
 
 int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
     if (scratch) {
@@ -742,11 +769,23 @@ int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, fl
         rc = conv_wgrad_fast(g, x, dy, dw, db, st, scratch);
         if (rc == ACLGAN_OK) db = nullptr;   // bias gradient fused into the tuned kernel
         if (rc == ACLGAN_EUNSUPPORTED) {
-            if (g.Co > 64) rc = launch_wgrad<2, 2, 2, 2>(g, p, st);       // 128 x 128
-            else if (g.Co > 32) rc = launch_wgrad<2, 2, 1, 2>(g, p, st);  // 64 x 128
-            else rc = launch_wgrad<1, 4, 1, 2>(g, p, st);                 // 32 x 256
+            void* det = nullptr;
+            if (deterministic()) {
+                if (!scratch) { set_error("conv_wgrad: deterministic mode needs the scratch buffer (aclgan_conv2d_wgrad_ws)"); return ACLGAN_EINVAL; }
+                det = scratch;
+            }
+            if (g.Co > 64) rc = launch_wgrad<2, 2, 2, 2>(g, p, st, det);       // 128 x 128
+            else if (g.Co > 32) rc = launch_wgrad<2, 2, 1, 2>(g, p, st, det);  // 64 x 128
+            else rc = launch_wgrad<1, 4, 1, 2>(g, p, st, det);                 // 32 x 256
         }
         if (rc) return rc;
+    }
+    if (db && deterministic()) {      // ordered column sums (the kernels below add their row blocks with fp32 atomics)
+        if (!scratch) { set_error("conv_wgrad: deterministic mode needs the scratch buffer (aclgan_conv2d_wgrad_ws)"); return ACLGAN_EINVAL; }
+        int splits, chunk;
+        wgrad_generic_plan(1, g.M, &splits, &chunk);
+        void* cs = (char*)scratch + (((size_t)(splits + 1) * g.Co * g.K * sizeof(float) + 255) & ~(size_t)255);
+        return colsum_ordered(dy, db, g.M, g.Co, cs, st);
     }
     if (db && g.Co % 4 == 0 && g.Co <= 1024 && (256 % (g.Co / 4)) == 0) {
         const int rows = 512;

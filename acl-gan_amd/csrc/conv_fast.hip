@@ -462,7 +462,8 @@ int launch_dgrad_fast(const ConvGeom& g, DgFP p, hipStream_t st) {
     // halo launches loop over the useful taps only (about 1 / taps-per-axis of them): plan the slices for that shorter loop --
     // every slice ends in 128 x 128 fp32 atomics, which is what the old 15-slice halo launch mostly consisted of
     const int nk_plan = (p.mode == 2 && p.band == 0) ? std::max(g.Co / 16, nk_min / ((g.k + g.s - 1) / g.s)) : nk_min;
-    if (nblk < 128 && nk_plan >= 32) p.ksplit = max(1, min(nk_plan / 8, 512 / nblk));   // floor: stay within one round of 512 resident workgroups
+    if (nblk < 128 && nk_plan >= 32 && !deterministic())       // (the slices combine with fp32 atomics)
+        p.ksplit = max(1, min(nk_plan / 8, 512 / nblk));   // floor: stay within one round of 512 resident workgroups
     if (p.ksplit > 1 && p.mode == 0) {
         hipError_t e = hipMemsetAsync(p.dxp, 0, conv_dgrad_scratch_bytes(g), st);
         if (e != hipSuccess) return hip_fail(e, "memset dxp");
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_fast_kernel(WgFP p) {
     const int pend = min(p.P, pbeg + p.chunk);
     if (pbeg >= pend) return;
     const int phase = p.phases ? (int)blockIdx.y : 0;
-    float* dwbase = p.dw + (size_t)phase * p.Co * p.Kn;
+    float* dwbase = p.dw + (size_t)phase * p.Co * p.Kn + (size_t)blockIdx.z * p.dw_zs;
     const int py = phase >> 1, px = phase & 1;
 
     // Per-pixel gather state of this block's pixel chunk, decoded ONCE into LDS (the old per-tile
@@ -670,7 +671,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad_fast_kernel(WgFP p) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < BK; ++r) t += red[r * BM + tid];
-            atomicAdd(p.db + m0 + tid, t);
+            atomicAdd(p.db + (size_t)blockIdx.z * p.db_zs + m0 + tid, t);
         }
     }
     const int l31 = lane & 31, lh = lane >> 5;
@@ -883,7 +884,7 @@ int launch_wgrad_kc_any(const ConvGeom& g, const WgFP& p, void* part, hipStream_
 }
 
 template <int WM, int WN, int TM, int TN>
-int launch_wgrad_fast(const ConvGeom& g, WgFP p, hipStream_t st) {
+int launch_wgrad_fast(const ConvGeom& g, WgFP p, hipStream_t st, void* det_part = nullptr) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     p.tiles_n = cdiv(p.Kn, BN);
     p.nwg = cdiv(g.Co, BM) * p.tiles_n;
@@ -896,12 +897,34 @@ int launch_wgrad_fast(const ConvGeom& g, WgFP p, hipStream_t st) {
     splits = max(splits, cdiv(p.P, 1024));                // the per-chunk pixel table lives in LDS (WG_MAX_CHUNK)
     p.chunk = cdiv(cdiv(p.P, splits), 16) * 16;
     splits = cdiv(p.P, p.chunk);
+    // deterministic mode: every pixel slice accumulates into its own zeroed copy of (dw, db), the copies are added in order
+    float* dw_out = p.dw; float* db_out = p.db;
+    const int64_t ndw = (int64_t)ny * g.Co * p.Kn;
+    if (det_part != nullptr && splits > 1) {
+        hipError_t e = hipMemsetAsync(det_part, 0, (size_t)splits * (ndw + g.Co) * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "memset wgrad slices");
+        p.dw = (float*)det_part; p.dw_zs = ndw;
+        if (p.db) { p.db = (float*)det_part + (size_t)splits * ndw; p.db_zs = g.Co; }
+    }
     static int nost = -1;
     if (nost < 0) { const char* e = getenv("ACLGAN_NOSINGLETAP"); nost = (e && atoi(e)) ? 1 : 0; }
     if (!nost && p.Ci % BN == 0) hipLaunchKernelGGL((conv_wgrad_fast_kernel<WM, WN, TM, TN, true>), dim3(p.nwg, ny, splits), dim3(WM * WN * 64), 0, st, p);
     else hipLaunchKernelGGL((conv_wgrad_fast_kernel<WM, WN, TM, TN, false>), dim3(p.nwg, ny, splits), dim3(WM * WN * 64), 0, st, p);
     ACL_CHECK_LAUNCH("conv_wgrad_fast_kernel");
+    if (p.dw_zs) {
+        int rc = reduce_slices_ordered(p.dw, ndw, splits, dw_out, st);
+        if (rc) return rc;
+        if (db_out) { rc = reduce_slices_ordered(p.db, g.Co, splits, db_out, st); if (rc) return rc; }
+    }
     return ACLGAN_OK;
+}
+// scratch of the deterministic mode of launch_wgrad_fast (upper bound over the tile shapes: the slice count only shrinks with them)
+size_t wgrad_fast_det_bytes(const ConvGeom& g, int Kn, int P, int ny) {
+    const int nwg = cdiv(g.Co, 128) * cdiv(Kn, 128);
+    int splits = std::max(1, 1536 / (nwg * ny));
+    splits = std::max(1, std::min(splits, cdiv(P, 256)));
+    splits = std::max(splits, cdiv(P, 1024)) + 1;
+    return (size_t)splits * ((size_t)ny * g.Co * Kn + g.Co) * sizeof(float) + 256;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1026,6 +1049,7 @@ size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled()) return 0;
     if (wgrad_kc_ok(g) && conv_wino_ok(g)) return conv_wgrad_wino_scratch_bytes(g);
     if (wgrad_kc_ok(g)) return ((wgrad_part_scratch(g, BK, WGKC_TARGET) + 255) & ~(size_t)255) + (up5_eligible(g) ? conv_up5_wino_wgrad_scratch_bytes(g) : 0);
+    if (deterministic()) return wgrad_fast_det_bytes(g, g.K, g.M, 1);      // atomics kernel with per-slice copies (the sub-pixel split is skipped)
     return conv_up5_scratch_bytes(g);
 }
 // forward scratch: merged phase weights + ring split-K partials (sub-pixel layers), or the split-K partials of a small-grid layer
@@ -1056,6 +1080,7 @@ int conv_up5_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx
 
 int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
     if (!fast_enabled() || !up5_eligible(g) || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
+    if (deterministic() && !wgrad_kc_ok(g)) return ACLGAN_EUNSUPPORTED;    // (the phase / ring launches of the atomics kernel share dw)
     if (g.Co > 64) return up5_wgrad_t<2, 2, 2, 2>(g, x, dy, dw, db, (float*)scratch, st);
     if (g.Co > 32) return up5_wgrad_t<2, 2, 1, 2>(g, x, dy, dw, db, (float*)scratch, st);
     return up5_wgrad_t<1, 4, 1, 2>(g, x, dy, dw, db, (float*)scratch, st);
@@ -1131,7 +1156,7 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
     if (!fast_enabled() || g.Co % 16 != 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     static int nodirect = -1;
     if (nodirect < 0) { const char* e = getenv("ACLGAN_NODIRECT"); nodirect = (e && atoi(e)) ? 1 : 0; }
-    if (nodirect) dx = nullptr;
+    if (nodirect || deterministic()) dx = nullptr;      // padded grid + fold: no mirrored-halo atomics
     DgFP p;
     p.dy = dy; p.w = w; p.dxp = dxp;
     p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.Ci = g.Ci; p.k = g.k; p.s = g.s; p.Hp = g.Hp; p.Wp = g.Wp;
@@ -1163,6 +1188,7 @@ int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int 
     return launch_wgrad_kc_any(g, p, part, st);
 }
 
+bool conv_wgrad_fast_supported(const ConvGeom& g) { return fast_enabled() && g.Co % 4 == 0 && g.Ci % 4 == 0; }
 int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
     if (!fast_enabled() || g.Co % 4 != 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     WgFP p;
@@ -1175,9 +1201,14 @@ int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* d
     // with a scratch buffer (always, inside the engine): k-contiguous tiles + ordered slices, reproducible bit for bit;
     // the scratch-less operator call keeps the atomics kernel
     if (wgrad_kc_ok(g) && (scratch || wgrad_part_scratch(g, BK, WGKC_TARGET) == 0)) return launch_wgrad_kc_any(g, p, scratch, st);
-    if (g.Co > 64) return launch_wgrad_fast<2, 2, 2, 2>(g, p, st);
-    if (g.Co > 32) return launch_wgrad_fast<2, 2, 1, 2>(g, p, st);
-    return launch_wgrad_fast<1, 4, 1, 2>(g, p, st);
+    void* det = nullptr;
+    if (deterministic()) {
+        if (!scratch) { set_error("conv_wgrad: deterministic mode needs the scratch buffer (aclgan_conv2d_wgrad_ws)"); return ACLGAN_EINVAL; }
+        det = scratch;
+    }
+    if (g.Co > 64) return launch_wgrad_fast<2, 2, 2, 2>(g, p, st, det);
+    if (g.Co > 32) return launch_wgrad_fast<2, 2, 1, 2>(g, p, st, det);
+    return launch_wgrad_fast<1, 4, 1, 2>(g, p, st, det);
 }
 
 }  // namespace aclgan

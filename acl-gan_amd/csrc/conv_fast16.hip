@@ -437,7 +437,7 @@ int launch_dgrad16(const ConvGeom& g, DgFP p, hipStream_t st) {
     const int nblk = p.nwg * g.s * g.s;
     p.ksplit = 1;
     const int nk_plan = (p.mode == 2 && p.band == 0) ? std::max(g.Co / (16 * KS), nk_min / ((g.k + g.s - 1) / g.s)) : nk_min;   // halo: useful taps only
-    if (nblk < 128 && nk_plan * KS >= 32) p.ksplit = max(1, min(nk_plan * KS / 8, 512 / nblk));
+    if (nblk < 128 && nk_plan * KS >= 32 && !deterministic()) p.ksplit = max(1, min(nk_plan * KS / 8, 512 / nblk));   // (slices combine with atomics)
     if (p.ksplit > 1 && p.mode == 1 && !p.accumulate) {
         hipError_t e = hipMemsetAsync(p.dxp, 0, (size_t)g.B * g.Hi * g.Wi * g.Ci * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "memset dx");
@@ -824,6 +824,16 @@ DgFP dg_params(const ConvGeom& g, const float* dy, const u16* w16t, float* dx) {
 
 template <class T>
 int dgrad16_t(const ConvGeom& g, const float* dy, const float* w, const u16* w16t, float* dx, int accumulate, void* scratch, hipStream_t st) {
+    if (deterministic()) {
+        // every padded-grid position has exactly one writer (no split-K, no mirrored halo); conv_fold gathers the reflection /
+        // upsample backward.  The sub-pixel layers run as the plain upsample + 5x5 convolution they are.
+        if (!scratch) { set_error("conv_dgrad16: deterministic mode needs the scratch buffer"); return ACLGAN_EINVAL; }
+        DgFP p = dg_params(g, dy, w16t, (float*)scratch);
+        p.mode = 0; p.accumulate = 0;
+        const int rc = launch_dgrad16_any<T>(g, p, st);
+        if (rc) return rc;
+        return conv_fold(g, (const float*)scratch, dx, accumulate, st);
+    }
     if (up5_eligible(g)) {
         if (!scratch || !w) { set_error("conv_dgrad16: the upsample+5x5 layer needs its scratch buffer and the fp32 weights"); return ACLGAN_EINVAL; }
         u16* wpt = (u16*)scratch;
@@ -911,7 +921,11 @@ size_t conv_fwd16_scratch_bytes(const ConvGeom& g) {
     if (up5_eligible(g)) return up5_w16_bytes(g) + fwd_partial_bytes(g, 2, fwd16_bk(g));
     return fwd_partial_bytes(g, 0, fwd16_bk(g));
 }
-size_t conv_dgrad16_scratch_bytes(const ConvGeom& g) { return dgrad16_ok(g) && up5_eligible(g) ? up5_w16_bytes(g) : 0; }
+size_t conv_dgrad16_scratch_bytes(const ConvGeom& g) {
+    if (!dgrad16_ok(g)) return 0;
+    if (deterministic()) return (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float);     // padded-grid gradient
+    return up5_eligible(g) ? up5_w16_bytes(g) : 0;
+}
 size_t conv_wgrad16_scratch_bytes(const ConvGeom& g) { return wgrad16_ok(g) ? wgrad16_scratch(g) : 0; }
 
 int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st,

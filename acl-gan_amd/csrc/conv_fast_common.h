@@ -64,6 +64,9 @@ struct FwdFP {
     // fs_* floats after those of slice 0.  0 = off.
     int fsl; long long fs_x, fs_w, fs_y;
     int fsx_mod;                 // > 0: the x operand of slice f is plane f % fsx_mod
+    // deterministic mode of the atomics kernel (conv_wgrad_fast_kernel): pixel slice z accumulates into its own zeroed copy
+    // dw + z*dw_zs / db + z*db_zs (one writer per element), reduce_slices_ordered adds the copies in order.  0 = shared dw / db.
+    long long dw_zs = 0, db_zs = 0;
 };
 
 __device__ __forceinline__ bool fwd_row(const FwdFP& p, int m, int& b, int& oy, int& ox) {
@@ -244,6 +247,9 @@ struct WgFP {
     // f start fs_x / fs_dy floats after those of slice 0; the result goes to dw + f*Co*Kn (like a phase).  0 = off.
     int fsl; long long fs_x, fs_dy;
     int fsx_mod;                 // > 0: the x operand of slice f is plane f % fsx_mod
+    // deterministic mode of the atomics kernel (conv_wgrad_fast_kernel): pixel slice z accumulates into its own zeroed copy
+    // dw + z*dw_zs / db + z*db_zs (one writer per element), reduce_slices_ordered adds the copies in order.  0 = shared dw / db.
+    long long dw_zs = 0, db_zs = 0;
 };
 
 __device__ __forceinline__ void wg_coord(const WgFP& p, int pix, int& b, int& oy, int& ox) {

@@ -436,14 +436,17 @@ __global__ void __launch_bounds__(448) conv_wgrad_thin_kernel(const float* __res
 }
 
 // dw += sum over workgroups of partial[wg][tap][lane][v]; grid = (49 taps, groups of workgroups), 256 threads = (lane, v)
+// gpart != nullptr (deterministic mode, first level): the group sums are stored as partials of the same layout, [group][tap][256],
+// and a second call with ONE group adds them in order -- no two workgroups ever add into the same dw element
 template <bool WIDE_X>
 __global__ void __launch_bounds__(256) conv_wgrad_thin_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                     int nwg, int per_group, int CN) {
+                                                                     int nwg, int per_group, int CN, float* __restrict__ gpart) {
     constexpr int K = 7;
     const int tap = blockIdx.x, l = threadIdx.x >> 2, v = threadIdx.x & 3;
     const int w0 = blockIdx.y * per_group, w1 = min(nwg, w0 + per_group);
     float s = 0.f;
     for (int w = w0; w < w1; ++w) s += partial[((size_t)w * K * K + tap) * 256 + threadIdx.x];
+    if (gpart) { gpart[((size_t)blockIdx.y * K * K + tap) * 256 + threadIdx.x] = s; return; }
     const int widec = 4 * (l >> 2) + v, thin = l & 3;
     if (thin < CN) {
         if (WIDE_X) atomicAdd(dw + ((size_t)thin * K * K + tap) * 64 + widec, s);
@@ -525,29 +528,46 @@ size_t conv_wgrad_small_scratch_bytes(const ConvGeom& g) {
     bool wx;
     if (!thin_wgrad_case(g, &wx)) return 0;
     const dim3 gr = thin_wgrad_grid(g, wx);
-    return (size_t)gr.x * gr.y * gr.z * 49 * 256 * sizeof(float);
+    const size_t nwg = (size_t)gr.x * gr.y * gr.z;
+    if (deterministic())       // + second-level partials + the ordered bias column sums
+        return (nwg + cdiv((int)nwg, 64)) * 49 * 256 * sizeof(float) + 256 + colsum_ordered_bytes(g.M, g.Co);
+    return nwg * 49 * 256 * sizeof(float);
 }
 
 int conv_wgrad_small(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
     if (!small_enabled() || g.s != 1 || g.up || g.k != 7 || g.p != 3 || g.Hi < 7 || g.Wi < 7) return ACLGAN_EUNSUPPORTED;
     bool wx = false;
     const bool thin = thin_wgrad_case(g, &wx);
+    const bool det = deterministic();
+    if (det && !scratch) { set_error("conv_wgrad: deterministic mode needs the scratch buffer (aclgan_conv2d_wgrad_ws)"); return ACLGAN_EINVAL; }
     if (thin && (dw != nullptr || !wx)) {
         ACL_REQUIRE(dw != nullptr, "conv_wgrad(thin): dw must be given");
         const dim3 gr = thin_wgrad_grid(g, wx);
         float* part = (float*)scratch;       // nullptr: atomics straight into dw (correct, slower)
+        const int nwg = gr.x * gr.y * gr.z, per_group = 64, ngroups = cdiv(nwg, per_group);
+        float* gpart = det ? part + (size_t)nwg * 49 * 256 : nullptr;
+        // deterministic mode: the fused bias sum of the kernel is a cross-workgroup atomic -> ordered column sums below instead
         if (wx) hipLaunchKernelGGL(conv_wgrad_thin_kernel<true>, gr, dim3(448), 0, st, x, dy, dw, (float*)nullptr, part, g.Hi, g.Wi, 4);
-        else hipLaunchKernelGGL(conv_wgrad_thin_kernel<false>, gr, dim3(448), 0, st, x, dy, dw, db, part, g.Hi, g.Wi, g.Ci);
+        else hipLaunchKernelGGL(conv_wgrad_thin_kernel<false>, gr, dim3(448), 0, st, x, dy, dw, det ? (float*)nullptr : db, part, g.Hi, g.Wi, g.Ci);
         ACL_CHECK_LAUNCH("conv_wgrad_thin_kernel");
         if (part) {
-            const int nwg = gr.x * gr.y * gr.z, per_group = 64;
-            if (wx) hipLaunchKernelGGL(conv_wgrad_thin_reduce_kernel<true>, dim3(49, cdiv(nwg, per_group)), dim3(256), 0, st, part, dw, nwg, per_group, 4);
-            else hipLaunchKernelGGL(conv_wgrad_thin_reduce_kernel<false>, dim3(49, cdiv(nwg, per_group)), dim3(256), 0, st, part, dw, nwg, per_group, g.Ci);
+            if (wx) hipLaunchKernelGGL(conv_wgrad_thin_reduce_kernel<true>, dim3(49, ngroups), dim3(256), 0, st, part, dw, nwg, per_group, 4, gpart);
+            else hipLaunchKernelGGL(conv_wgrad_thin_reduce_kernel<false>, dim3(49, ngroups), dim3(256), 0, st, part, dw, nwg, per_group, g.Ci, gpart);
             ACL_CHECK_LAUNCH("conv_wgrad_thin_reduce_kernel");
+            if (gpart) {
+                if (wx) hipLaunchKernelGGL(conv_wgrad_thin_reduce_kernel<true>, dim3(49, 1), dim3(256), 0, st, gpart, dw, ngroups, ngroups, 4, (float*)nullptr);
+                else hipLaunchKernelGGL(conv_wgrad_thin_reduce_kernel<false>, dim3(49, 1), dim3(256), 0, st, gpart, dw, ngroups, ngroups, g.Ci, (float*)nullptr);
+                ACL_CHECK_LAUNCH("conv_wgrad_thin_reduce_kernel(groups)");
+            }
         }
-        if (!wx) return ACLGAN_OK;           // bias gradient fused (wide = dy)
+        if (!wx && !det) return ACLGAN_OK;           // bias gradient fused (wide = dy)
+        if (det) {
+            if (!db) return ACLGAN_OK;
+            char* cs = (char*)scratch + ((size_t)(nwg + ngroups) * 49 * 256 * sizeof(float) + 255) / 256 * 256;
+            return colsum_ordered(dy, db, g.M, g.Co, cs, st);
+        }
     } else {
-        if (g.Co != 4 || g.Ci != 64) return ACLGAN_EUNSUPPORTED;
+        if (g.Co != 4 || g.Ci != 64 || det) return ACLGAN_EUNSUPPORTED;     // (deterministic mode: the general kernels with slice copies)
         if (dw) {
             const int Hp = g.Hi + 6, rows = 8;
             hipLaunchKernelGGL(conv_wgrad_co4_kernel<7>, dim3(cdiv(Hp, rows), 7, g.B), dim3(256), 0, st, x, dy, dw, g.Hi, g.Wi, rows);

@@ -346,8 +346,19 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_in_kernel(const float2*
     if (db) db[(size_t)b * w_stride + c] += s1;
 }
 
+// dgamma[c] += sum_b s2[b][c], dbeta[c] += sum_b s1[b][c] from sbc [B][C][2]: fixed order, reproducible bit for bit
+__global__ void __launch_bounds__(256) norm_bwd_ln_params_kernel(const float* __restrict__ sbc, int B, int C, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) { s1 += sbc[2 * (b * C + c)]; s2 += sbc[2 * (b * C + c) + 1]; }
+    if (dbeta) dbeta[c] += s1;
+    if (dgamma) dgamma[c] += s2;
+}
+
 // LN: one workgroup per sample: per-(b,c) totals of the chunk partials, the per-sample sums S1_b, S2_b,
-// the coefficients, and the parameter gradients (atomically accumulated over samples).
+// the coefficients.  The parameter gradients are summed over the samples, in order, by norm_bwd_ln_params_kernel.
 __global__ void __launch_bounds__(256) norm_bwd_finalize_ln_kernel(const float2* __restrict__ part, int B, int C, int HW,
                                                                    int nchunks, const float* __restrict__ gamma,
                                                                    const float* __restrict__ rstd, float* __restrict__ cA,
@@ -381,9 +392,7 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_ln_kernel(const float2*
         if (kl == 0) {
             for (int j = 1; j < KL; ++j) { s1 += r1[j * CL + cl]; s2 += r2[j * CL + cl]; }
             sbc[2 * (b * C + c)] = s1; sbc[2 * (b * C + c) + 1] = s2;
-            if (dbeta) atomicAdd(dbeta + c, s1);
-            if (dgamma) atomicAdd(dgamma + c, s2);
-            const float g = gamma[c];
+            const float g = gamma[c];      // (dgamma / dbeta: norm_bwd_ln_params_kernel adds the samples in order)
             a1 += g * s1; a2 += g * s2;
         }
     }
@@ -457,6 +466,10 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const float* x, const floa
         float* sbc = cC + (size_t)B * C;   // [B][C][2] totals (scratch tail, see norm_scratch_bytes)
         hipLaunchKernelGGL(norm_bwd_finalize_ln_kernel, dim3(B), dim3(256), 0, st, part, B, C, HW, nchunks, w, rstd, cA, cB, cC, dw, db, sbc);
         ACL_CHECK_LAUNCH("norm_bwd_finalize_ln_kernel");
+        if (dw || db) {
+            hipLaunchKernelGGL(norm_bwd_ln_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sbc, B, C, dw, db);
+            ACL_CHECK_LAUNCH("norm_bwd_ln_params_kernel");
+        }
     } else {
         const float* ww = kind == ACLGAN_NORM_ADAIN ? w : nullptr;
     hipLaunchKernelGGL(norm_bwd_finalize_in_kernel, dim3(cdiv(C, 16), B), dim3(256), 0, st, part, C, HW, nchunks, ww, w_stride,

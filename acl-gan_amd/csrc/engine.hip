@@ -771,8 +771,14 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
                               L + fl[i].size_slot, L + fl[i].digit_slot, fl[i].a->g, c.st, c.lscale, ftot ? ftot + 2 * i : nullptr,
                               npix * (int64_t)c.sync_world));
     // identity losses (trainer.py:162-165)
-    RUN(l1_loss(rA4->d, 4, xa->d, npix, L + ACLGAN_L_IDT_A, rA4->g, hp.recon_x_w, 1, c.st, c.lscale));
-    RUN(l1_loss(rB4->d, 4, xb->d, npix, L + ACLGAN_L_IDT_B, rB4->g, hp.recon_x_w, 1, c.st, c.lscale));
+    {
+        const size_t mark = c.top;
+        float* l1p = c.allocf(2 * L1_PART_FLOATS);     // workgroup partials of the two L1 sums: added in a fixed order
+        NEED(l1p);
+        RUN(l1_loss(rA4->d, 4, xa->d, npix, L + ACLGAN_L_IDT_A, rA4->g, hp.recon_x_w, 1, c.st, c.lscale, l1p));
+        RUN(l1_loss(rB4->d, 4, xb->d, npix, L + ACLGAN_L_IDT_B, rB4->g, hp.recon_x_w, 1, c.st, c.lscale, l1p + L1_PART_FLOATS));
+        c.top = mark;
+    }
     if (!c.dry) {
         hipLaunchKernelGGL(gen_total_kernel, dim3(1), dim3(1), 0, c.st, L, hp, ftot ? fscale / (float)c.sync_world : fscale);
         ACL_CHECK_LAUNCH("gen_total_kernel");

@@ -278,7 +278,7 @@ int linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, c
         ACL_CHECK_LAUNCH("linear_dw_kernel");
     }
     if (dx) {
-        int slices = O >= 512 ? std::min(64, O / 64) : 1;
+        int slices = (O >= 512 && !deterministic()) ? std::min(64, O / 64) : 1;     // O-slices combine with fp32 atomics: one slice in deterministic mode
         const int oslice = cdiv(O, slices);
         slices = cdiv(O, oslice);
         if (slices > 1) { rc = fill_zero(dx, (int64_t)B * I, st); if (rc) return rc; }
@@ -389,6 +389,63 @@ int focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg,
     return ACLGAN_OK;
 }
 
+// ---- ordered reductions of the deterministic mode (common.h) ----
+__global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int64_t n, int nslices, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = part[i];
+        for (int z = 1; z < nslices; ++z) s += part[(size_t)z * n + i];
+        out[i] += s;
+    }
+}
+int reduce_slices_ordered(const float* part, int64_t n, int nslices, float* out, hipStream_t st) {
+    if (n <= 0 || nslices <= 0) return ACLGAN_OK;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, part, n, nslices, out);
+    ACL_CHECK_LAUNCH("reduce_slices_kernel");
+    return ACLGAN_OK;
+}
+// part[chunk][c] = sum of dy[r][c] over the chunk's rows r (one thread per channel walks its rows in order: coalesced along c)
+static const int COLSUM_ROWS = 256;
+__global__ void __launch_bounds__(256) colsum_chunks_kernel(const float* __restrict__ dy, float* __restrict__ part, int64_t M, int C) {
+    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS, r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += gridDim.y * 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int64_t r = r0;
+        for (; r + 3 < r1; r += 4) {
+            s0 += dy[(size_t)r * C + c]; s1 += dy[(size_t)(r + 1) * C + c];
+            s2 += dy[(size_t)(r + 2) * C + c]; s3 += dy[(size_t)(r + 3) * C + c];
+        }
+        for (; r < r1; ++r) s0 += dy[(size_t)r * C + c];
+        part[(size_t)blockIdx.x * C + c] = (s0 + s1) + (s2 + s3);
+    }
+}
+// two ordered levels: chunk partials -> groups of 64 chunks -> db
+size_t colsum_ordered_bytes(int64_t M, int C) {
+    const int64_t chunks = cdiv64(M, COLSUM_ROWS), groups = cdiv64(chunks, 64);
+    return (size_t)(chunks + groups) * C * sizeof(float) + 256;
+}
+__global__ void __launch_bounds__(256) colsum_groups_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t chunks, int C, int per, int add) {
+    const int64_t k0 = (int64_t)blockIdx.x * per, k1 = k0 + per < chunks ? k0 + per : chunks;
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += gridDim.y * 256) {
+        float s = 0.f;
+        for (int64_t k = k0; k < k1; ++k) s += part[(size_t)k * C + c];
+        if (add) out[c] += s; else out[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+int colsum_ordered(const float* dy, float* db, int64_t M, int C, void* scratch, hipStream_t st) {
+    ACL_REQUIRE(dy && db && scratch && M > 0 && C > 0, "colsum_ordered: bad arguments");
+    const int64_t chunks = cdiv64(M, COLSUM_ROWS), groups = cdiv64(chunks, 64);
+    float* part = (float*)scratch;
+    float* gpart = part + (size_t)chunks * C;
+    const int cy = std::max(1, std::min(cdiv(C, 256), 8));
+    hipLaunchKernelGGL(colsum_chunks_kernel, dim3((unsigned)chunks, cy), dim3(256), 0, st, dy, part, M, C);
+    ACL_CHECK_LAUNCH("colsum_chunks_kernel");
+    hipLaunchKernelGGL(colsum_groups_kernel, dim3((unsigned)groups, cy), dim3(256), 0, st, part, gpart, chunks, C, 64, 0);
+    ACL_CHECK_LAUNCH("colsum_groups_kernel");
+    hipLaunchKernelGGL(colsum_groups_kernel, dim3(1, cy), dim3(256), 0, st, gpart, db, groups, C, (int)groups, 1);
+    ACL_CHECK_LAUNCH("colsum_groups_kernel(final)");
+    return ACLGAN_OK;
+}
+
 // ---- LSGAN: loss_slot += weight*mean((o-t)^2); d_o = gscale*weight*2(o-t)/n ----
 __global__ void __launch_bounds__(256) lsgan_kernel(const float* __restrict__ o, int n, float target, float weight, float* loss_slot,
                                                     float* __restrict__ d_o, float gscale, const float* __restrict__ lscale) {
@@ -411,7 +468,8 @@ int lsgan_loss(const float* o, int n, float target, float weight, float* loss_sl
 
 // ---- L1: loss_slot += mean|a[:, :3] - b|; d_a[pix][0..2] (+)= gscale*sign/N, channel 3 untouched (a_stride 4) ----
 __global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ a, int a_stride, const float* __restrict__ b, int64_t npix,
-                                                 float* loss_slot, float* __restrict__ d_a, float gscale, int d_acc, const float* __restrict__ lscale) {
+                                                 float* loss_slot, float* __restrict__ d_a, float gscale, int d_acc, const float* __restrict__ lscale,
+                                                 float* __restrict__ part) {
     float s = 0.f;
     if (lscale) gscale *= lscale[0];
     const float inv = 1.f / (3.f * (float)npix);
@@ -428,11 +486,29 @@ __global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ a, in
         if (d_a && !d_acc && a_stride == 4) d_a[i * 4 + 3] = 0.f;
     }
     s = block_sum_t0(s);
-    if (threadIdx.x == 0) atomicAdd(loss_slot, s * inv);
+    if (threadIdx.x == 0) {
+        if (part) part[blockIdx.x] = s;           // ordered finish (l1_finish_kernel): the loss value is reproducible bit for bit
+        else atomicAdd(loss_slot, s * inv);
+    }
 }
-int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st, const float* lscale) {
-    hipLaunchKernelGGL(l1_kernel, dim3((int)std::min<int64_t>(cdiv64(npix, 256), 1024)), dim3(256), 0, st, a, a_stride, b, npix, loss_slot, d_a, gscale, d_accumulate, lscale);
+__global__ void __launch_bounds__(256) l1_finish_kernel(const float* __restrict__ part, int nblocks, float inv, float* loss_slot) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += part[i];     // fixed assignment of partials to threads, fixed tree below
+    s = block_sum_t0(s);
+    if (threadIdx.x == 0) loss_slot[0] += s * inv;
+}
+// part (optional): L1_PART_FLOATS floats of scratch -> the workgroup partials are added in a fixed order; without it the workgroups
+// add into the slot with fp32 atomics (one workgroup in deterministic mode)
+int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st,
+            const float* lscale, float* part) {
+    int blocks = (int)std::min<int64_t>(cdiv64(npix, 256), L1_PART_FLOATS);
+    if (!part && deterministic()) blocks = 1;
+    hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, st, a, a_stride, b, npix, loss_slot, d_a, gscale, d_accumulate, lscale, part);
     ACL_CHECK_LAUNCH("l1_kernel");
+    if (part) {
+        hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, st, part, blocks, 1.f / (3.f * (float)npix), loss_slot);
+        ACL_CHECK_LAUNCH("l1_finish_kernel");
+    }
     return ACLGAN_OK;
 }
 

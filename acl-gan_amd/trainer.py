@@ -181,7 +181,7 @@ class aclgan_Trainer:
     ``z=(z_1, z_2, z_3)`` on the update calls for seed-independent parity tests (by default z is
     drawn from the CPU generator exactly like trainer.py:99-101)."""
 
-    def __init__(self, hyperparameters, device=None, compute_dtype=None):
+    def __init__(self, hyperparameters, device=None, compute_dtype=None, deterministic=None):
         if not torch.cuda.is_available():
             raise L.AclganError("aclgan_Trainer needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
         hp = hyperparameters
@@ -191,6 +191,13 @@ class aclgan_Trainer:
         self.compute_dtype = str(compute_dtype or hp.get("compute_dtype", "fp32"))
         if self.compute_dtype not in L.DTYPE:
             raise L.AclganError("compute_dtype=%r: expected one of %s" % (self.compute_dtype, sorted(L.DTYPE)))
+        # deterministic=True (or config key "deterministic", or ACLGAN_DETERMINISTIC=1): every reduction takes an ordered path and a step
+        # is reproducible bit for bit run to run (include/aclgan_hip.h: aclgan_set_deterministic).  Process-wide, like
+        # torch.use_deterministic_algorithms; must be chosen before the workspaces are sized, i.e. here.
+        det = deterministic if deterministic is not None else hp.get("deterministic", None)
+        if det is not None:
+            L.check(L.lib.aclgan_set_deterministic(1 if det else 0), "set_deterministic")
+        self.deterministic = bool(L.lib.aclgan_get_deterministic())
         self._ctx = C.c_void_p()
         L.check(L.lib.aclgan_ctx_create(C.byref(self.arch), C.byref(self._ctx)), "ctx_create")
         L.check(L.lib.aclgan_set_compute_dtype(self._ctx, L.DTYPE[self.compute_dtype]), "set_compute_dtype")

@@ -136,9 +136,9 @@ def dominant_kernel_probe(L, dtype, reps=20):
         nb = L.lib.aclgan_conv2d_fwd_scratch_bytes(C.byref(d))
         scr = torch.empty(nb // 4 + 64, device="cuda")
         # the ResBlock convolution as the step runs it (with scratch): Winograd F(4x4,3x3) = filter / input transform, 36 batched
-        # GEMMs on conv_fwd_fast_kernel<2,2,2,2,3>, output transform.  achieved = ALGORITHMIC (direct-convolution) FLOPs / time.
+        # GEMMs on conv_fwd_fast_kernel<2,2,1,2,4> (64 x 128 tiles), output transform.  achieved = ALGORITHMIC (direct-convolution) FLOPs / time.
         call = lambda: L.check(L.lib.aclgan_conv2d_fwd_ws(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(scr), st))   # noqa: E731
-        name = "ResBlock conv 8x64x64x256->256 3x3 forward (Winograd F(4x4,3x3): 4 launches, GEMMs on conv_fwd_fast_kernel<2,2,2,2,3>)"
+        name = "ResBlock conv 8x64x64x256->256 3x3 forward (Winograd F(4x4,3x3): 4 launches, GEMMs on conv_fwd_fast_kernel<2,2,1,2,4>)"
         # algorithmic bytes = input + weights + output; HBM-side traffic of the Winograd pipeline adds the V / M planes (2 x 75 MB
         # written and read once each, mostly served by the 256 MB Infinity Cache) -- not re-measured with PMC this round
         wino = os.environ.get("ACLGAN_NOWINO", "0") in ("", "0")
@@ -326,7 +326,10 @@ def main():
                          "flop_per_launch": tflop_img * B * 1e12, "launch": "one dis_update+gen_update step (per GPU)",
                          "event_ms_per_step": round(ev_ms / args.steps, 3),
                          "executed_flop_per_launch": tflop_exec * B * 1e12, "executed_achieved": round(tflop_exec * B / step_s, 2),
-                         "executed_frac": round(tflop_exec * B / step_s / peak, 4)},
+                         "executed_frac": round(tflop_exec * B / step_s / peak, 4),
+                         "note": ("achieved/frac = ALGORITHMIC work (SURVEY 8d: direct-convolution FLOPs of the step) over the dense MFMA peak; "
+                                  "the fp32 path runs the 3x3 ResBlock convolutions and the sub-pixel phases with Winograd F(4x4,3x3) "
+                                  "(1/4 of their MACs), so frac can exceed 1 -- executed_* is what the MFMA pipes really issue")},
         }
         if args.dtype != "fp32":
             out["config"]["precision"] = ("heavy convolutions: %s operands on v_mfma_f32_32x32x16, fp32 accumulate; fp32 master weights, "

@@ -113,6 +113,17 @@ typedef struct aclgan_ctx aclgan_ctx;
 /* ---- library ---- */
 int aclgan_version(void);
 const char* aclgan_last_error(void);
+/* Deterministic mode (process-wide; also ACLGAN_DETERMINISTIC=1; the counterpart of torch.use_deterministic_algorithms, which the
+ * reference never turns on -- its cuDNN backward is not reproducible either, train.py:29 sets cudnn.benchmark = True).
+ * Default (0): the forward, the losses and the weight gradients of the heavy layers are reproducible bit for bit; the reflection
+ * halo / small-grid split-K of the input gradients and the weight gradients of the thin and odd-channel layers combine partial
+ * sums with fp32 atomics (reproducible to ~1e-7).  on != 0: those take ordered paths (padded-grid gradient + fold gather, one
+ * private copy of dw per pixel slice added in order, ordered column sums): a step is reproducible bit for bit run to run, at a
+ * measured cost of a few %.  Scratch sizes depend on the mode: set it BEFORE any *_scratch_bytes /
+ * *_workspace_bytes query, and pass the scratch buffers (the scratch-less operator calls refuse to run where they would need
+ * atomics). */
+int aclgan_set_deterministic(int on);
+int aclgan_get_deterministic(void);
 
 /* ---- context: replaces aclgan_Trainer.__init__ network construction (trainer.py:15-23) ---- */
 int aclgan_ctx_create(const aclgan_arch* arch, aclgan_ctx** out);

@@ -1,0 +1,182 @@
+"""Deterministic mode (aclgan_set_deterministic / aclgan_Trainer(deterministic=True)): every reduction that the default plan
+combines with fp32 atomics takes an ordered path, so results are reproducible BIT FOR BIT run to run -- and still the same
+numbers (oracle parity within the usual tolerances).
+
+The reference has no such mode (train.py:29 sets cudnn.benchmark = True and never calls torch.use_deterministic_algorithms);
+this is the SURVEY section 7 item "split-K + deterministic reduction" taken to the whole step.
+
+  * operator level: input and weight gradients of every kernel family that uses atomics by default (reflection halo, small-grid
+    split-K, the sub-pixel ring, thin 7x7 layers, 3- / 6-channel first layers, the Cout = 1 head, reduced widths), fp32 and
+    the 16-bit dgrad: oracle parity + two calls agree bitwise;
+  * step level: dis_update + gen_update of two trainers built from the same state agree bitwise in all 16 losses and every
+    gradient tensor (fp32 and bf16), and agree with the default mode to the tolerance of the full-size parity tests.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import aclgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd import _lib
+    return _lib
+
+
+@pytest.fixture()
+def det(L):
+    """deterministic mode for one test; the process-wide switch is restored afterwards"""
+    L.check(L.lib.aclgan_set_deterministic(1))
+    assert L.lib.aclgan_get_deterministic() == 1
+    yield
+    L.check(L.lib.aclgan_set_deterministic(0))
+
+
+# (B, Hi, Wi, Ci, Co, k, s, p, up): one per default-mode atomics site
+DET_CASES = [
+    (2, 8, 8, 256, 256, 3, 1, 1, 0),      # ResBlock conv: Winograd interior + halo launch  -> padded grid + fold
+    (2, 10, 12, 64, 64, 3, 1, 1, 0),      # direct interior + halo
+    (2, 8, 8, 256, 128, 5, 1, 2, 1),      # sub-pixel layer: ring contributions via atomics  -> plain upsample+5x5 dgrad
+    (2, 9, 13, 32, 48, 5, 1, 2, 1),       # sub-pixel layer without the ordered-slice wgrad kernel (Cin 32, Cout 48)
+    (2, 8, 8, 256, 512, 4, 2, 1, 0),      # late discriminator conv: small grid, split-K dgrad
+    (2, 32, 32, 6, 64, 4, 2, 1, 0),       # first discriminator layer, 6 channels: general wgrad kernel, column-sum bias gradient
+    (2, 32, 32, 3, 64, 4, 2, 1, 0),       # same, 3 channels
+    (2, 4, 4, 512, 1, 1, 1, 0, 0),        # discriminator head, Cout 1
+    (2, 16, 20, 3, 64, 7, 1, 3, 0),       # thin 7x7 encoder layer (4x4x1 MFMA kernel, per-workgroup partials)
+    (2, 16, 16, 64, 4, 7, 1, 3, 0),       # thin 7x7 output layer, Cout 4
+    (3, 12, 20, 16, 8, 4, 2, 1, 0),       # reduced width: atomics weight-gradient kernel with pixel slices
+    (5, 9, 7, 12, 20, 3, 1, 1, 0),        # nothing a multiple of anything
+]
+
+
+def _tensors(case, seed):
+    B, Hi, Wi, Ci, Co, k, s, p, up = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Ci, Hi, Wi, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (2.0 / (Ci * k * k)) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    return x, w, b
+
+
+@pytest.mark.parametrize("case", DET_CASES)
+def test_conv_backward_reproducible(L, det, case):
+    from gpu_util import conv_desc, gpu_conv_dgrad, gpu_conv_wgrad, nhwc, nchw, ohwi, rel_err
+    B, Hi, Wi, Ci, Co, k, s, p, up = case
+    x, w, b = _tensors(case, 3)
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y = O.conv_block(x, w, b, s, p, "none", upsample=bool(up))
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(4))
+    y.backward(dy)
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, "none")
+    xg, wg, dyg = nhwc(x.detach()).cuda(), ohwi(w.detach()).cuda(), nhwc(dy).cuda()
+    dx1 = gpu_conv_dgrad(L, d, dyg, wg)
+    dx2 = gpu_conv_dgrad(L, d, dyg, wg)
+    assert rel_err(nchw(dx1), x.grad) < TOL
+    assert torch.equal(dx1, dx2)
+    dw1, db1 = gpu_conv_wgrad(L, d, xg, dyg)
+    dw2, db2 = gpu_conv_wgrad(L, d, xg, dyg)
+    assert rel_err(dw1, ohwi(w.grad)) < TOL and rel_err(db1, b.grad) < TOL
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    # accumulate mode of the input gradient goes through the same ordered path
+    base = torch.randn(B, Hi, Wi, Ci, generator=torch.Generator().manual_seed(6))
+    acc = gpu_conv_dgrad(L, d, dyg, wg, accumulate_into=base.clone().cuda())
+    assert rel_err(nchw(acc).cpu() - nchw(base), x.grad) < 5 * TOL
+
+
+def test_scratchless_calls_refuse_where_they_would_need_atomics(L, det):
+    from gpu_util import conv_desc, nhwc
+    d = conv_desc(L, 2, 32, 32, 6, 64, 4, 2, 1, 0, "none")
+    x = torch.randn(2, 32, 32, 6, device="cuda"); dy = torch.randn(2, 16, 16, 64, device="cuda")
+    dw = torch.zeros(64, 4, 4, 6, device="cuda"); db = torch.zeros(64, device="cuda")
+    rc = L.lib.aclgan_conv2d_wgrad(C.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.stream_ptr())
+    assert rc != 0 and b"deterministic" in L.lib.aclgan_last_error()
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 8, 8, 256, 256, 3, 1, 1, 0), (2, 8, 8, 256, 128, 5, 1, 2, 1), (2, 8, 8, 256, 512, 4, 2, 1, 0)])
+def test_conv_dgrad16_reproducible(L, det, case, dt):
+    from gpu_util import conv_desc, nhwc, nchw, ohwi, rel_err
+    B, Hi, Wi, Ci, Co, k, s, p, up = case
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    x, w, b = _tensors(case, 8)
+    xr = x.double().requires_grad_(True)
+    y = O.conv_block(xr, w.to(tdt).double(), b.double(), s, p, "none", upsample=bool(up))
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    y.backward(dy.to(tdt).double())
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, "none")
+    wg, dyg = ohwi(w).cuda(), nhwc(dy).cuda()
+    w16t = torch.empty(wg.numel(), dtype=torch.int16, device="cuda")
+    L.check(L.lib.aclgan_pack_weights16(L.ptr(wg), None, L.ptr(w16t), Co, k * k, Ci, L.DTYPE[dt], L.stream_ptr()), "pack_weights16")
+    nb = L.lib.aclgan_conv2d_dgrad16_scratch_bytes(C.byref(d))
+    assert nb >= 4 * B * ((Hi << up) + 2 * p) * ((Wi << up) + 2 * p) * Ci     # the padded-grid gradient
+    scr = torch.empty(nb // 4 + 64, device="cuda")
+    outs = []
+    for _ in range(2):
+        dx = torch.full((B, Hi, Wi, Ci), float("nan"), device="cuda")
+        L.check(L.lib.aclgan_conv2d_dgrad16(C.byref(d), L.DTYPE[dt], L.ptr(dyg), L.ptr(wg), L.ptr(w16t), L.ptr(dx), 0, L.ptr(scr),
+                                            L.stream_ptr()), "conv2d_dgrad16")
+        outs.append(dx)
+    # exact-arithmetic check (operands rounded on both sides): the plain upsample+5x5 gradient merges no filters, so it holds
+    # for the sub-pixel layers too
+    assert rel_err(nchw(outs[0]), xr.grad) < TOL
+    assert torch.equal(outs[0], outs[1])
+
+
+def _step(T, cfg, nets, x_a, x_b, z, dtype, deterministic):
+    out = {}
+    for which in ("dis", "gen"):
+        tr = T.aclgan_Trainer(cfg, compute_dtype=dtype, deterministic=deterministic)
+        assert tr.deterministic == bool(deterministic)
+        for name in O.OracleTrainer.NETS:
+            getattr(tr, name).load_state_dict(nets[name], strict=False)
+        if which == "dis":
+            tr.dis_update(x_a, x_b, cfg, z=z[:3]); names = ("dis_A", "dis_B", "dis_2")
+        else:
+            tr.gen_update(x_a, x_b, cfg, z=z[3:]); names = ("gen_AB", "gen_BA")
+        torch.cuda.synchronize()
+        from aclgan_amd import _lib
+        lnames = _lib.LOSS_NAMES[12:16] if which == "dis" else _lib.LOSS_NAMES[0:12]
+        out[which] = ({n: float(getattr(tr, n)) for n in lnames},
+                      {(n, k): g.contiguous().clone() for n in names for k, g in getattr(tr, n).named_grads()})
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_step_reproducible_bit_for_bit(L, dtype):
+    from aclgan_amd import trainer as T
+    cfg = O.default_config()
+    cfg["display_size"] = 1
+    cfg["focus_epsilon"] = 0.5
+    nets = O.test_nets(cfg, 0)
+    g = torch.Generator().manual_seed(21)
+    B, S = 2, 128
+    x_a = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    x_b = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    z = [torch.randn(B, 8, 1, 1, generator=g) for _ in range(6)]
+    try:
+        a = _step(T, cfg, nets, x_a, x_b, z, dtype, True)
+        b = _step(T, cfg, nets, x_a, x_b, z, dtype, True)
+    finally:
+        L.check(L.lib.aclgan_set_deterministic(0))
+    ref = _step(T, cfg, nets, x_a, x_b, z, dtype, False)
+    for which in ("dis", "gen"):
+        la, ga = a[which]; lb, gb = b[which]; lr, gr = ref[which]
+        assert la and ga
+        assert la == lb, (which, {k: (la[k], lb[k]) for k in la if la[k] != lb[k]})
+        diff = [k for k in ga if not torch.equal(ga[k], gb[k])]
+        assert not diff, (which, diff[:8])
+        # same numbers as the default plan (different summation order only; ReLU mask flips bound the tail like in
+        # tests/test_gpu_fullsize.py)
+        gmax = max(float(t.double().norm()) for t in gr.values())
+        worst = max(((ga[k].double() - gr[k].double()).norm().item() / (gr[k].double().norm().item() + 1e-5 * gmax / 1e-2), k) for k in ga)
+        assert worst[0] <= (1e-2 if dtype == "fp32" else 0.3), worst
+        for k in la:
+            assert abs(la[k] - lr[k]) <= (5e-3 if k.endswith("_size") else 1e-4 if dtype == "fp32" else 2e-3) * max(1e-3, abs(lr[k])), (k, la[k], lr[k])
