@@ -529,7 +529,7 @@ int conv_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, vo
     p.dy = dy; p.w = w; p.dxp = (float*)scratch;
     p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.Ci = g.Ci; p.k = g.k; p.s = g.s; p.Hp = g.Hp; p.Wp = g.Wp;
     p.Hc = cdiv(g.Hp, g.s); p.Wc = cdiv(g.Wp, g.s); p.Mc = g.B * p.Hc * p.Wc; p.tiles_n = 0; p.nwg = 0;
-    if (!deterministic()) {     // (deterministic mode: the padded-grid path below -- one writer per element, then the fold gather)
+    {
         const int rc0 = conv_up5_dgrad(g, dy, w, dx, accumulate, scratch, st);
         if (rc0 != ACLGAN_EUNSUPPORTED) return rc0;
     }

@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
                 if (mk) atomicOr(&tap_mask, mk);
             }
             if (py < p.Hp && px < p.Wp) {
-                if (p.mode == 0) oo = (b * p.Hp + py) * p.Wp + px;
+                if (p.mode == 0 || p.ringpad) oo = (b * p.Hp + py) * p.Wp + px;
                 else oo = (b * p.Hd + (refl(py - p.pad, p.Hi) >> p.upshift)) * p.Wd + (refl(px - p.pad, p.Wi) >> p.upshift);   // mode 1: identity inside
                 // merged launch: interior pixels that also receive mirrored halo rows are combined with atomics (bit 30)
                 if (merged && p.mode == 1 && (dg_is_target(py - p.pad, p.Hi, p.pad) || dg_is_target(px - p.pad, p.Wi, p.pad))) oo |= 1 << 30;
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
                 if (of >= 0) {
                     const int oo = of & ~(1 << 30);
                     float* o = p.dxp + (size_t)oo * p.Ci + n;
-                    if (p.ksplit > 1 || p.mode == 2 || (of >> 30)) atomicAdd(o, acc[i][j][r]);   // split-K partials / mirrored halo / its targets
+                    if (p.ksplit > 1 || (p.mode == 2 && !p.ringpad) || (of >> 30)) atomicAdd(o, acc[i][j][r]);   // split-K partials / mirrored halo / its targets
                     else if (p.accumulate) *o += acc[i][j][r];
                     else *o = acc[i][j][r];
                 }
@@ -488,7 +488,7 @@ int launch_dgrad_fast_merged(const ConvGeom& g, DgFP p, hipStream_t st) {
     // epilogue of the interior tiles costs more than the 36-48 us launch it removes: fp32 step 171.7 -> 182.5 ms.
     static int off = -1;
     if (off < 0) { const char* e = getenv("ACLGAN_MERGEDHALO"); off = (e && atoi(e)) ? 0 : 1; }
-    if (off || g.p == 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
+    if (off || deterministic() || g.p == 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     int mi = 0, mh = 0;
     for (int cy = 0; cy < g.s; ++cy)
         for (int cx = 0; cx < g.s; ++cx) {
@@ -516,7 +516,9 @@ int launch_dgrad_fast_merged(const ConvGeom& g, DgFP p, hipStream_t st) {
 
 template <int WM, int WN, int TM, int TN>
 int dgrad_fast_all(const ConvGeom& g, DgFP p, float* dxp, float* dx, int accumulate, bool* direct, hipStream_t st) {
-    if (g.up == 0 && dx != nullptr) {
+    // deterministic mode: the Winograd layers keep their fast interior and fold the ring in order (below); every other layer
+    // takes the padded-grid plan -- one launch, one writer per element, then the fold gather
+    if (g.up == 0 && dx != nullptr && (!deterministic() || g.p == 0 || (dxp && conv_wino_ok(g)))) {
         // interior positions straight into dx (balanced grid, no scratch round trip) and the halo ring mirrored in with
         // atomics: together = dgrad + reflection_pad2d backward
         *direct = true;
@@ -527,6 +529,16 @@ int dgrad_fast_all(const ConvGeom& g, DgFP p, float* dxp, float* dx, int accumul
         rc = (dxp && conv_wino_ok(g)) ? conv_dgrad_wino_interior(g, p.dy, p.w, dx, accumulate, dxp, st)   // interior: Winograd (zero pad, flipped w^T)
                                       : launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
         if (rc) return rc;
+        if (g.p > 0 && deterministic()) {
+            // ordered reflection backward: the ring positions are STORED on a zeroed padded grid (one writer each; the scratch is
+            // free again -- the Winograd planes of the interior are consumed) and conv_fold adds them onto their targets
+            hipError_t e = hipMemsetAsync(dxp, 0, (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float), st);
+            if (e != hipSuccess) return hip_fail(e, "memset padded grid");
+            p.mode = 2; p.ringpad = 1; p.dxp = dxp; p.accumulate = 0;
+            rc = launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
+            if (rc) return rc;
+            return conv_fold(g, dxp, dx, 1, st);
+        }
         if (g.p > 0) { p.mode = 2; rc = launch_dgrad_fast<WM, WN, TM, TN>(g, p, st); }
         return rc;
     }
@@ -1029,6 +1041,15 @@ int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, i
     p.Ho = g.Ho; p.Wo = g.Wo; p.k = 5; p.s = 1; p.Hp = g.Hp; p.Wp = g.Wp; p.Hc = g.Hp; p.Wc = g.Wp;
     p.mode = 2; p.accumulate = 1; p.pad = 2; p.Hi = g.Hu; p.Wi = g.Wu;
     p.dyv = 0; p.band = 6; p.upshift = 1; p.Hd = g.Hi; p.Wd = g.Wi;
+    if (deterministic()) {     // band positions stored on a zeroed padded hi-res grid (after the merged filters), then the fold gather
+        float* dxp = (float*)((char*)wp + up5_merged_bytes(g));
+        hipError_t e = hipMemsetAsync(dxp, 0, (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "memset padded grid");
+        p.ringpad = 1; p.dxp = dxp; p.accumulate = 0;
+        const int rc = launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
+        if (rc) return rc;
+        return conv_fold(g, dxp, dx, 1, st);
+    }
     return launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
 }
 
@@ -1041,7 +1062,8 @@ size_t conv_up5_scratch_bytes(const ConvGeom& g) {
 // dgrad of a sub-pixel layer: merged phase filters, then the Winograd planes of its four phases
 size_t conv_up5_dgrad_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled() || !up5_eligible(g)) return 0;
-    return up5_merged_bytes(g) + conv_up5_wino_dgrad_scratch_bytes(g);
+    const size_t padded = deterministic() ? (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float) : 0;     // ordered ring fold
+    return up5_merged_bytes(g) + std::max(conv_up5_wino_dgrad_scratch_bytes(g), padded);
 }
 // weight-gradient scratch of the tuned kernels: phase gradients of the sub-pixel layers + the partial tiles of the
 // ordered-slice kernel (0 when neither applies)
@@ -1156,7 +1178,8 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
     if (!fast_enabled() || g.Co % 16 != 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     static int nodirect = -1;
     if (nodirect < 0) { const char* e = getenv("ACLGAN_NODIRECT"); nodirect = (e && atoi(e)) ? 1 : 0; }
-    if (nodirect || deterministic()) dx = nullptr;      // padded grid + fold: no mirrored-halo atomics
+    if (nodirect) dx = nullptr;
+    if (deterministic() && !dxp) { set_error("conv_dgrad: deterministic mode needs the scratch buffer"); return ACLGAN_EINVAL; }
     DgFP p;
     p.dy = dy; p.w = w; p.dxp = dxp;
     p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.Ci = g.Ci; p.k = g.k; p.s = g.s; p.Hp = g.Hp; p.Wp = g.Wp;

@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
                 if (mk) atomicOr(&tap_mask, mk);
             }
             if (py < p.Hp && px < p.Wp) {
-                if (p.mode == 0) oo = (b * p.Hp + py) * p.Wp + px;
+                if (p.mode == 0 || p.ringpad) oo = (b * p.Hp + py) * p.Wp + px;
                 else oo = (b * p.Hd + (refl(py - p.pad, p.Hi) >> p.upshift)) * p.Wd + (refl(px - p.pad, p.Wi) >> p.upshift);   // mode 1: identity inside
                 // merged launch: interior pixels that also receive mirrored halo rows are combined with atomics (bit 30)
                 if (merged && p.mode == 1 && (dg_is_target(py - p.pad, p.Hi, p.pad) || dg_is_target(px - p.pad, p.Wi, p.pad))) oo |= 1 << 30;
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad16_kernel(DgFP pk) {
                 if (of >= 0) {
                     const int oo = of & ~(1 << 30);
                     float* o = p.dxp + (size_t)oo * p.Ci + n;
-                    if (p.ksplit > 1 || p.mode == 2 || (of >> 30)) atomicAdd(o, acc[i][j][r]);   // split-K partials / mirrored halo / its targets
+                    if (p.ksplit > 1 || (p.mode == 2 && !p.ringpad) || (of >> 30)) atomicAdd(o, acc[i][j][r]);   // split-K partials / mirrored halo / its targets
                     else if (p.accumulate) *o += acc[i][j][r];
                     else *o = acc[i][j][r];
                 }
@@ -456,7 +456,7 @@ int launch_dgrad16_merged(const ConvGeom& g, DgFP p, hipStream_t st) {
     // epilogue of the interior tiles costs more than the 36-48 us launch it removes: fp32 step 171.7 -> 182.5 ms.
     static int off = -1;
     if (off < 0) { const char* e = getenv("ACLGAN_MERGEDHALO"); off = (e && atoi(e)) ? 0 : 1; }
-    if (off || g.p == 0) return ACLGAN_EUNSUPPORTED;
+    if (off || deterministic() || g.p == 0) return ACLGAN_EUNSUPPORTED;
     int mi = 0, mh = 0;
     for (int cy = 0; cy < g.s; ++cy)
         for (int cx = 0; cx < g.s; ++cx) {
@@ -826,7 +826,8 @@ template <class T>
 int dgrad16_t(const ConvGeom& g, const float* dy, const float* w, const u16* w16t, float* dx, int accumulate, void* scratch, hipStream_t st) {
     if (deterministic()) {
         // every padded-grid position has exactly one writer (no split-K, no mirrored halo); conv_fold gathers the reflection /
-        // upsample backward.  The sub-pixel layers run as the plain upsample + 5x5 convolution they are.
+        // upsample backward.  The sub-pixel layers run as the plain upsample + 5x5 convolution they are: at 16-bit MFMA rates
+        // one launch over the padded grid beats interior + zeroed ring + accumulate-fold (measured: bf16 step 76.8 vs 81.2 ms).
         if (!scratch) { set_error("conv_dgrad16: deterministic mode needs the scratch buffer"); return ACLGAN_EINVAL; }
         DgFP p = dg_params(g, dy, w16t, (float*)scratch);
         p.mode = 0; p.accumulate = 0;

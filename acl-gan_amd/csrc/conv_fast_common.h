@@ -173,6 +173,10 @@ struct DgFP {
     // ring (mode 2).  Interior pixels that are mirror targets of the reflection are combined with atomics by both kinds of
     // tile (the caller zeroes that frame first unless it accumulates); all other pixels keep plain stores.
     int Ti;
+    // deterministic mode: ringpad = 1 makes a mode-2 launch STORE each ring position at its padded-grid index of dxp (a zeroed
+    // [B][Hp][Wp][Ci] scratch; every position has one writer) instead of adding it onto its mirror target with atomics;
+    // conv_fold(accumulate) then gathers the ring into dx in a fixed order
+    int ringpad = 0;
 };
 
 // image rows / columns that receive mirrored halo gradients (reflection pad p on a size-n axis): padded -j -> j, n-1+j -> n-1-j

@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch; default: 8 (BASELINE configs[1], [2]), 32 with --dtype fp16 (configs[4]: 256 over 8 GPUs)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="compute dtype of the heavy convolutions")
+    ap.add_argument("--deterministic", action="store_true", help="ordered reductions everywhere (bit-reproducible step); default: the fast plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -240,7 +241,7 @@ def main():
     cfg = male2female_config()
     cfg["display_size"] = 1
     torch.manual_seed(0)       # (replicas are made identical by the trainer's rank-0 broadcast, not by this seed)
-    tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype)
+    tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, deterministic=True if args.deterministic else None)
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1 + rank)   # each rank its own shard of the synthetic global batch
     x_a = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
@@ -270,6 +271,7 @@ def main():
     for i in range(args.steps):
         step()
         evs[i + 1].record()
+    t_enq = time.perf_counter() - t0      # every launch of the K steps is queued here; the GPU is still working
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -317,9 +319,12 @@ def main():
                        "dist_backend": dist.get_backend() if use_dist else None, "replicas_identical": replicas_identical,
                        "grad_allreduce": ("overlapped with backward (bucket callback)" if getattr(tr, "_reducer", None) is not None else
                                           ("after backward" if use_dist else "none (1 GPU)")),
-                       "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),
+                       "deterministic": bool(tr.deterministic), "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),
                        "ms_per_step_min_max": [round(min(per_step), 3), round(max(per_step), 3)],
                        "ms_dis_update": round(t_dis, 2), "ms_gen_update": round(t_gen, 2),
+                       # host time to ENQUEUE a step (tape build + ~2000 launches): the floor a HIP graph would remove; the step is
+                       # GPU-bound while this stays below ms_per_step
+                       "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 2),
                        "reference_cadence_D1_G2_images_per_s": round(world * B / ((t_dis + 0.5 * t_gen) / 1e3), 2)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": None,

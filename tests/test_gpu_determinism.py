@@ -108,6 +108,7 @@ def test_conv_dgrad16_reproducible(L, det, case, dt):
     tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dt]
     x, w, b = _tensors(case, 8)
     xr = x.double().requires_grad_(True)
+    assert L.lib.aclgan_conv16_eligible(C.byref(conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, "none")), 1) == 1
     y = O.conv_block(xr, w.to(tdt).double(), b.double(), s, p, "none", upsample=bool(up))
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
     y.backward(dy.to(tdt).double())
