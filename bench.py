@@ -301,6 +301,25 @@ def main():
         ev3[2].record(); torch.cuda.synchronize()
         t_dis += ev3[0].elapsed_time(ev3[1]) / 2; t_gen += ev3[1].elapsed_time(ev3[2]) / 2
 
+    # launch-bound floor (outside the timed region, rank 0): the same step on 64x64 B=1 images -- the same ~2000 launches and the
+    # same host-side tape, next to no GPU work -- costs what the host needs to enqueue a step; this is what a HIP graph would remove
+    launch_floor_ms = None
+    if rank == 0:
+        try:
+            g2 = torch.Generator().manual_seed(3)
+            xs = torch.rand(1, 3, 64, 64, generator=g2).cuda() * 2 - 1
+            z1 = [torch.randn(1, cfg["gen"]["style_dim"], 1, 1, generator=g2) for _ in range(3)]
+            tr2 = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype)
+            for i in range(6):
+                if i == 2:
+                    torch.cuda.synchronize(); tf0 = time.perf_counter()
+                tr2.dis_update(xs, xs, cfg, z=z1); tr2.gen_update(xs, xs, cfg, z=z1)
+            torch.cuda.synchronize()
+            launch_floor_ms = (time.perf_counter() - tf0) * 1e3 / 4
+            del tr2
+        except Exception as e:      # informational only
+            log("launch floor probe failed: %r" % (e,))
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
@@ -322,9 +341,10 @@ def main():
                        "deterministic": bool(tr.deterministic), "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),
                        "ms_per_step_min_max": [round(min(per_step), 3), round(max(per_step), 3)],
                        "ms_dis_update": round(t_dis, 2), "ms_gen_update": round(t_gen, 2),
-                       # host time to ENQUEUE a step (tape build + ~2000 launches): the floor a HIP graph would remove; the step is
-                       # GPU-bound while this stays below ms_per_step
+                       # host time until the K steps were queued (the HIP queue back-pressures, so this tracks the GPU when it is the
+                       # bottleneck) and the launch-bound floor: the whole step on 64x64 B=1 images, i.e. ~2000 tiny launches (what a HIP graph could approach)
                        "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 2),
+                       "launch_bound_floor_ms_per_step": None if launch_floor_ms is None else round(launch_floor_ms, 2),
                        "reference_cadence_D1_G2_images_per_s": round(world * B / ((t_dis + 0.5 * t_gen) / 1e3), 2)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": None,
