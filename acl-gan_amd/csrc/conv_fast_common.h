@@ -64,9 +64,6 @@ struct FwdFP {
     // fs_* floats after those of slice 0.  0 = off.
     int fsl; long long fs_x, fs_w, fs_y;
     int fsx_mod;                 // > 0: the x operand of slice f is plane f % fsx_mod
-    // deterministic mode of the atomics kernel (conv_wgrad_fast_kernel): pixel slice z accumulates into its own zeroed copy
-    // dw + z*dw_zs / db + z*db_zs (one writer per element), reduce_slices_ordered adds the copies in order.  0 = shared dw / db.
-    long long dw_zs = 0, db_zs = 0;
 };
 
 __device__ __forceinline__ bool fwd_row(const FwdFP& p, int m, int& b, int& oy, int& ox) {
