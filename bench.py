@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="compute dtype of the heavy convolutions")
     ap.add_argument("--deterministic", action="store_true", help="ordered reductions everywhere (bit-reproducible step); default: the fast plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-floor", action="store_true", help="skip the 64x64 B=1 launch-bound probe (keeps kernel traces clean)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -304,7 +305,7 @@ def main():
     # launch-bound floor (outside the timed region, rank 0): the same step on 64x64 B=1 images -- the same ~2000 launches and the
     # same host-side tape, next to no GPU work -- costs what the host needs to enqueue a step; this is what a HIP graph would remove
     launch_floor_ms = None
-    if rank == 0:
+    if world == 1 and not args.no_launch_floor:      # (a second trainer would enter the data-parallel broadcast on one rank only)
         try:
             g2 = torch.Generator().manual_seed(3)
             xs = torch.rand(1, 3, 64, 64, generator=g2).cuda() * 2 - 1
