@@ -311,15 +311,20 @@ __global__ void __launch_bounds__(256) wino_outgrad_kernel(const float* __restri
     }
     if (bpart) *reinterpret_cast<F*>(bpart + ((size_t)blockIdx.y * (nth / Cv) + gid / Cv) * C + c) = bs;     // [ph][row = gid / Cv][c]
 }
-// db[c] += sum over the partial rows, in a fixed order: 16 channels x 16 row groups per workgroup, groups combined through LDS
-__global__ void __launch_bounds__(256) wino_bias_finish_kernel(const float* __restrict__ bpart, int rows, int C, float* __restrict__ db) {
+// Ordered column sums of the partial rows: 16 channels x 16 row groups per workgroup, groups combined through LDS.  blockIdx.y =
+// row slice: with `level2 != nullptr` the slice sums are STORED at level2[slice][c] (first level of a two-level reduction -- the
+// sub-pixel layers produce 32 768 partial rows for 64 channels, far too long a serial walk for four workgroups); else db[c] += sum.
+__global__ void __launch_bounds__(256) wino_bias_finish_kernel(const float* __restrict__ bpart, int rows, int C, float* __restrict__ db,
+                                                               float* __restrict__ level2) {
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    const int per = (rows + 15) >> 4;
+    const int per_slice = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per_slice, r1 = min(rows, r0 + per_slice);
+    const int per = (max(r1 - r0, 0) + 15) >> 4;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < C) {
-        const int jb = rg * per, je = min(rows, jb + per);
+        const int jb = r0 + rg * per, je = min(r1, jb + per);
         int j = jb;
         for (; j + 3 < je; j += 4) {
             s0 += bpart[(size_t)j * C + c]; s1 += bpart[(size_t)(j + 1) * C + c];
@@ -333,7 +338,8 @@ __global__ void __launch_bounds__(256) wino_bias_finish_kernel(const float* __re
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
-        db[c] += t;
+        if (level2) level2[(size_t)blockIdx.y * C + c] = t;
+        else db[c] += t;
     }
 }
 // dw[co][ky][kx][ci] += (G^T dU G)[ky][kx] of dU[f][co][ci]
@@ -379,6 +385,7 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 int grid_for(int64_t n, int cap) { return (int)std::min<int64_t>(cdiv64(n, 256), cap); }
 const int WINO_BIAS_BLOCKS = 1024;       // x 256 threads: a multiple of every channel-group count in {16 .. 256}
 const size_t WINO_BPART_BYTES = (size_t)WINO_BIAS_BLOCKS * 256 * 4 * sizeof(float);     // bias partial rows of one phase (4 channels per thread)
+const size_t WINO_L2_BYTES = (size_t)64 * 1024 * sizeof(float);                          // second-level partials: 64 slices x up to 1024 channels
 
 // channels per thread of the transform kernels (ACLGAN_WINO_VEC = 1 | 2 | 4; 2 measured best, profiles/r02_experiments.md)
 int wino_vec() {
@@ -417,6 +424,19 @@ int launch_wino_outgrad(const float* dy, float* dM, float* bpart, int B, const W
     else if (nv == 2) hipLaunchKernelGGL(wino_outgrad_kernel<2>, grid, dim3(256), 0, st, dy, dM, bpart, B, vs, C, TY, TX);
     else hipLaunchKernelGGL(wino_outgrad_kernel<1>, grid, dim3(256), 0, st, dy, dM, bpart, B, vs, C, TY, TX);
     ACL_CHECK_LAUNCH("wino_outgrad_kernel");
+    return ACLGAN_OK;
+}
+// level2: WINO_BIAS_SLICES * C floats (carved from the tail of the partial buffer's allocation)
+const int WINO_BIAS_SLICES = 64;
+int launch_wino_bias_finish(const float* bpart, int rows, int C, float* db, float* level2, hipStream_t st) {
+    if (rows >= 1024) {
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(C, 16), WINO_BIAS_SLICES), dim3(256), 0, st, bpart, rows, C, (float*)nullptr, level2);
+        ACL_CHECK_LAUNCH("wino_bias_finish_kernel(level 1)");
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(C, 16), 1), dim3(256), 0, st, level2, WINO_BIAS_SLICES, C, db, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(C, 16), 1), dim3(256), 0, st, bpart, rows, C, db, (float*)nullptr);
+    }
+    ACL_CHECK_LAUNCH("wino_bias_finish_kernel");
     return ACLGAN_OK;
 }
 bool wino_bias_ok(int C) { const int Cv = C / wino_vec(); return C % wino_vec() == 0 && (256 % Cv == 0 || Cv % 256 == 0); }
@@ -478,7 +498,7 @@ size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
     return align256((size_t)36 * T * g.Ci * 4) + align256((size_t)36 * T * g.Co * 4) + align256((size_t)36 * g.Co * g.Ci * 4) +
-           align256(WINO_BPART_BYTES) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
+           align256(WINO_BPART_BYTES + WINO_L2_BYTES) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
 }
 int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
@@ -489,7 +509,7 @@ int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* d
     float* V = take(cur, (size_t)36 * T * g.Ci * 4);
     float* dM = take(cur, (size_t)36 * T * g.Co * 4);
     float* dU = take(cur, (size_t)36 * g.Co * g.Ci * 4);
-    float* bpart = take(cur, WINO_BPART_BYTES);
+    float* bpart = take(cur, WINO_BPART_BYTES + WINO_L2_BYTES);
     void* part = cur;
     const WViews vw = one_view(ident_view(g.Hi, g.Wi));
     int rc0 = launch_wino_input(x, V, g.B, vw, 1, g.Ci, TY, TX, -1, 1, st);
@@ -498,8 +518,8 @@ int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* d
     rc0 = launch_wino_outgrad(dy, dM, db ? bpart : (float*)nullptr, g.B, vw, 1, g.Co, TY, TX, st, &brows);
     if (rc0) return rc0;
     if (db) {
-        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, brows, g.Co, db);
-        ACL_CHECK_LAUNCH("wino_bias_finish_kernel");
+        const int rcb = launch_wino_bias_finish(bpart, brows, g.Co, db, bpart + WINO_BPART_BYTES / sizeof(float), st);
+        if (rcb) return rcb;
     }
     hipError_t e = hipMemsetAsync(dU, 0, (size_t)36 * g.Co * g.Ci * sizeof(float), st);
     if (e != hipSuccess) return hip_fail(e, "memset dU");
@@ -582,7 +602,7 @@ size_t conv_up5_wino_wgrad_scratch_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     const Up5Geo q = up5_geo(g);
     return align256((size_t)36 * q.T * g.Ci * 4) + align256((size_t)144 * q.T * g.Co * 4) + align256((size_t)144 * g.Co * g.Ci * 4) +
-           align256(4 * WINO_BPART_BYTES) + gemm_at_b_slices_scratch((int)q.T, g.Co, g.Ci, 144) + 256;
+           align256(4 * WINO_BPART_BYTES + WINO_L2_BYTES) + gemm_at_b_slices_scratch((int)q.T, g.Co, g.Ci, 144) + 256;
 }
 int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st) {
     if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !wino_bias_ok(g.Co)) return ACLGAN_EUNSUPPORTED;
@@ -591,7 +611,7 @@ int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* d
     float* V = take(cur, (size_t)36 * q.T * g.Ci * 4);
     float* dM = take(cur, (size_t)144 * q.T * g.Co * 4);
     float* dU = take(cur, (size_t)144 * g.Co * g.Ci * 4);
-    float* bpart = take(cur, 4 * WINO_BPART_BYTES);
+    float* bpart = take(cur, 4 * WINO_BPART_BYTES + WINO_L2_BYTES);
     void* part = cur;
     int rc0 = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
     if (rc0) return rc0;
@@ -599,8 +619,8 @@ int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* d
     rc0 = launch_wino_outgrad(dy, dM, db ? bpart : (float*)nullptr, g.B, q.ph, 4, g.Co, q.TY, q.TX, st, &brows);
     if (rc0) return rc0;
     if (db) {      // interior pixels (the four phases); the ring launch of the caller adds the ring pixels
-        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cdiv(g.Co, 16)), dim3(256), 0, st, bpart, 4 * brows, g.Co, db);
-        ACL_CHECK_LAUNCH("wino_bias_finish_kernel(up5)");
+        const int rcb = launch_wino_bias_finish(bpart, 4 * brows, g.Co, db, bpart + 4 * WINO_BPART_BYTES / sizeof(float), st);
+        if (rcb) return rcb;
     }
     hipError_t e = hipMemsetAsync(dU, 0, (size_t)144 * g.Co * g.Ci * sizeof(float), st);
     if (e != hipSuccess) return hip_fail(e, "memset dU");

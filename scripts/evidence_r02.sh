@@ -56,4 +56,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
     python scripts/pmc_dump.py $DB "" >> $O/pmc_winograd_traffic.txt 2>&1
 done
 cat $O/pmc_winograd_traffic.txt | cut -c 1-160 | tee -a $O/progress.log
+echo "== PMC: MFMA pipe of the Winograd GEMM slices (fwd, wgrad)" | tee -a $O/progress.log
+for w in fwd wgrad; do
+    rm -rf /tmp/pmc_sq_$w
+    timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA -d /tmp/pmc_sq_$w -o p -- python scripts/probe_wino.py $w > /dev/null 2>&1
+    DB=$(find /tmp/pmc_sq_$w -name "*.db" | head -1)
+    echo "## $w" >> $O/pmc_winograd_mfma.txt
+    python scripts/pmc_dump.py $DB "" >> $O/pmc_winograd_mfma.txt 2>&1
+done
+cat $O/pmc_winograd_mfma.txt | cut -c 1-160 | tee -a $O/progress.log
 echo "== done" | tee -a $O/progress.log

@@ -10,7 +10,8 @@ for r in rows:
     name = r[ci.get("kernel_name", ci.get("name", 0))] if ("kernel_name" in ci or "name" in ci) else "?"
     if pat not in str(name): continue
     cn = r[ci["counter_name"]]; v = r[ci["value"]]
-    a = agg.setdefault((re.sub(r"\(.*$", "", str(name))[:60], cn), [0, 0.0]); a[0] += 1; a[1] += v
+    short = str(name).replace("(anonymous namespace)::", "").replace("aclgan::", "").replace("void ", "")
+    a = agg.setdefault((re.sub(r"\(.*$", "", short)[:60], cn), [0, 0.0]); a[0] += 1; a[1] += v
 for (k, cn), (n, v) in sorted(agg.items()):
     print("%-62s %-28s n=%d avg=%.4g" % (k, cn, n, v / n))
 if not agg: print("columns:", cols)
