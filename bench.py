@@ -144,7 +144,7 @@ def dominant_kernel_probe(L, dtype, reps=20):
         wino = os.environ.get("ACLGAN_NOWINO", "0") in ("", "0")
         # memory-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside the timed
         # process): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, summed over the four launches of the pipeline
-        extra = {"traffic": 463.0e6 if wino else 240.6e6, "algorithmic_bytes": 69.5e6,
+        extra = {"traffic": 469.0e6 if wino else 240.6e6, "algorithmic_bytes": 69.5e6,
                  "traffic_source": "profiles/r02_hbm_traffic_winograd.txt" if wino else "profiles/r01_hbm_traffic_conv_fwd.txt",
                  "executed_flop_per_launch": flop_direct * 0.25 if wino else flop_direct}
     else:

@@ -10,9 +10,11 @@ export TMPDIR=/tmp
 B="python bench.py --no-cpu-baseline"
 
 echo "== tests" | tee $O/progress.log
+if [ -z "${SKIP_TESTS:-}" ]; then
 (timeout 1500 python -m pytest tests -m gpu -q -s -x 2>&1 | grep -vE "^\s*$" | cut -c 1-600) > $O/tests_full.log
-tail -3 $O/tests_full.log | tee -a $O/progress.log
+grep -E "passed|failed" $O/tests_full.log | tail -2 | tee -a $O/progress.log
 grep -E "worst|passed|failed" $O/tests_full.log > $O/tests_summary.log
+fi
 
 echo "== smoke" | tee -a $O/progress.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) | tee $O/smoke.log
@@ -47,22 +49,6 @@ for cfg in "fp32:" "bf16:--dtype bf16" "fp32_512:--size 512 --batch 4"; do
     head -8 $O/kernel_stats_$tag.txt | cut -c 1-140 | tee -a $O/progress.log
 done
 
-echo "== PMC: memory-side bytes of the Winograd forward pipeline" | tee -a $O/progress.log
-for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_$c
-    timeout 300 rocprofv3 --pmc $c -d /tmp/pmc_$c -o p -- python scripts/probe_wino.py fwd > /dev/null 2>&1
-    DB=$(find /tmp/pmc_$c -name "*.db" | head -1)
-    echo "## $c" >> $O/pmc_winograd_traffic.txt
-    python scripts/pmc_dump.py $DB "" >> $O/pmc_winograd_traffic.txt 2>&1
-done
-cat $O/pmc_winograd_traffic.txt | cut -c 1-160 | tee -a $O/progress.log
-echo "== PMC: MFMA pipe of the Winograd GEMM slices (fwd, wgrad)" | tee -a $O/progress.log
-for w in fwd wgrad; do
-    rm -rf /tmp/pmc_sq_$w
-    timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA -d /tmp/pmc_sq_$w -o p -- python scripts/probe_wino.py $w > /dev/null 2>&1
-    DB=$(find /tmp/pmc_sq_$w -name "*.db" | head -1)
-    echo "## $w" >> $O/pmc_winograd_mfma.txt
-    python scripts/pmc_dump.py $DB "" >> $O/pmc_winograd_mfma.txt 2>&1
-done
-cat $O/pmc_winograd_mfma.txt | cut -c 1-160 | tee -a $O/progress.log
+echo "== PMC (Winograd pipeline: memory-side bytes, MFMA pipe)" | tee -a $O/progress.log
+bash scripts/evidence_r02_pmc.sh | tee -a $O/progress.log
 echo "== done" | tee -a $O/progress.log
