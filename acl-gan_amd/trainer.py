@@ -181,7 +181,7 @@ class aclgan_Trainer:
     ``z=(z_1, z_2, z_3)`` on the update calls for seed-independent parity tests (by default z is
     drawn from the CPU generator exactly like trainer.py:99-101)."""
 
-    def __init__(self, hyperparameters, device=None, compute_dtype=None, deterministic=None):
+    def __init__(self, hyperparameters, device=None, compute_dtype=None, deterministic=None, hip_graph=None):
         if not torch.cuda.is_available():
             raise L.AclganError("aclgan_Trainer needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
         hp = hyperparameters
@@ -198,6 +198,13 @@ class aclgan_Trainer:
         if det is not None:
             L.check(L.lib.aclgan_set_deterministic(1 if det else 0), "set_deterministic")
         self.deterministic = bool(L.lib.aclgan_get_deterministic())
+        # hip_graph=True (or config key "hip_graph", or ACLGAN_GRAPH=1): the launch sequence of an update (zero_grad + forward +
+        # losses + backward, ~1 000-2 000 kernels) is captured once per (shape, hyper-parameters, workspace) into a HIP graph and
+        # replayed; Adam stays a separate launch (its step count is a kernel argument).  Same kernels in the same order: same
+        # results.  Pays when the step is launch-bound (small batches / images); off by default.
+        hg = hip_graph if hip_graph is not None else hp.get("hip_graph", os.environ.get("ACLGAN_GRAPH", "0") not in ("", "0"))
+        self.hip_graph = bool(hg)
+        self._graphs = {}
         self._ctx = C.c_void_p()
         L.check(L.lib.aclgan_ctx_create(C.byref(self.arch), C.byref(self._ctx)), "ctx_create")
         L.check(L.lib.aclgan_set_compute_dtype(self._ctx, L.DTYPE[self.compute_dtype]), "set_compute_dtype")
@@ -420,11 +427,14 @@ class aclgan_Trainer:
         with torch.cuda.device(self.device):
             self._ensure_workspace(B, H, W)
             st = self._st()
-            L.check(L.lib.aclgan_zero_grad(self._ctx, grp, st), "zero_grad")   # opt.zero_grad() (trainer.py:91,248)
             fn = L.lib.aclgan_gen_update if which == "gen" else L.lib.aclgan_dis_update
-            if self._reducer is not None:
-                self._reducer.begin(grp)
-            L.check(fn(self._ctx, L.ptr(x_a), L.ptr(x_b), L.ptr(zz), B, H, W, C.byref(hpc), L.ptr(self._losses), st), which + "_update")
+            if self.hip_graph and self._reducer is None and self._run_graph(which, grp, fn, x_a, x_b, zz, B, H, W, hpc):
+                pass        # zero_grad + update replayed from the captured graph
+            else:
+                L.check(L.lib.aclgan_zero_grad(self._ctx, grp, st), "zero_grad")   # opt.zero_grad() (trainer.py:91,248)
+                if self._reducer is not None:
+                    self._reducer.begin(grp)
+                L.check(fn(self._ctx, L.ptr(x_a), L.ptr(x_b), L.ptr(zz), B, H, W, C.byref(hpc), L.ptr(self._losses), st), which + "_update")
             if getattr(self, "_sync_error", None) is not None:
                 raise self._sync_error
             self._allreduce_grads(grp)
@@ -436,6 +446,34 @@ class aclgan_Trainer:
             self._publish_losses(0, 12)
         else:
             self._publish_losses(12, 16)
+
+    # ---- HIP-graph replay of an update (opt-in, see __init__) ----
+    def _run_graph(self, which, grp, fn, x_a, x_b, zz, B, H, W, hpc):
+        """True: the update ran as a graph replay.  False: run it eagerly (first call of a new key -- it also performs the
+        library's one-time initialisation outside any capture -- or capture is unavailable)."""
+        key = (B, H, W, bytes(hpc), self._ws.data_ptr(), self._ws.numel(), self.compute_dtype, self.deterministic)
+        ent = self._graphs.get(which)
+        if ent is None or ent["key"] != key:
+            self._graphs[which] = {"key": key, "graph": None}
+            return False
+        if ent["graph"] is None:
+            try:
+                sx_a, sx_b, szz = torch.empty_like(x_a), torch.empty_like(x_b), torch.empty_like(zz)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st = self._st()      # the capture stream
+                    L.check(L.lib.aclgan_zero_grad(self._ctx, grp, st), "zero_grad (capture)")
+                    L.check(fn(self._ctx, L.ptr(sx_a), L.ptr(sx_b), L.ptr(szz), B, H, W, C.byref(hpc), L.ptr(self._losses), st), which + "_update (capture)")
+                ent.update(graph=g, x_a=sx_a, x_b=sx_b, zz=szz)
+            except Exception as e:      # capture unsupported here: say so once and stay eager
+                import warnings
+                warnings.warn("aclgan_Trainer: HIP-graph capture failed (%r); running eagerly" % (e,))
+                self.hip_graph = False
+                self._graphs = {}
+                return False
+        ent["x_a"].copy_(x_a); ent["x_b"].copy_(x_b); ent["zz"].copy_(zz)
+        ent["graph"].replay()
+        return True
 
     # ---- data parallelism (not in the reference, SURVEY.md 8e): one process per GPU, full replicas ----
     def _dist_world(self):

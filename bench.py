@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="compute dtype of the heavy convolutions")
     ap.add_argument("--deterministic", action="store_true", help="ordered reductions everywhere (bit-reproducible step); default: the fast plan")
+    ap.add_argument("--graph", action="store_true", help="replay each update from a captured HIP graph (launch-bound regimes: small batches / images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-floor", action="store_true", help="skip the 64x64 B=1 launch-bound probe (keeps kernel traces clean)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -242,7 +243,8 @@ def main():
     cfg = male2female_config()
     cfg["display_size"] = 1
     torch.manual_seed(0)       # (replicas are made identical by the trainer's rank-0 broadcast, not by this seed)
-    tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, deterministic=True if args.deterministic else None)
+    tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, deterministic=True if args.deterministic else None,
+                        hip_graph=True if args.graph else None)
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1 + rank)   # each rank its own shard of the synthetic global batch
     x_a = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
@@ -310,7 +312,7 @@ def main():
             g2 = torch.Generator().manual_seed(3)
             xs = torch.rand(1, 3, 64, 64, generator=g2).cuda() * 2 - 1
             z1 = [torch.randn(1, cfg["gen"]["style_dim"], 1, 1, generator=g2) for _ in range(3)]
-            tr2 = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype)
+            tr2 = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, hip_graph=True if args.graph else None)
             for i in range(6):
                 if i == 2:
                     torch.cuda.synchronize(); tf0 = time.perf_counter()
@@ -339,7 +341,8 @@ def main():
                        "dist_backend": dist.get_backend() if use_dist else None, "replicas_identical": replicas_identical,
                        "grad_allreduce": ("overlapped with backward (bucket callback)" if getattr(tr, "_reducer", None) is not None else
                                           ("after backward" if use_dist else "none (1 GPU)")),
-                       "deterministic": bool(tr.deterministic), "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),
+                       "deterministic": bool(tr.deterministic), "hip_graph": bool(tr.hip_graph and tr._graphs.get("gen", {}).get("graph") is not None),
+                       "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),
                        "ms_per_step_min_max": [round(min(per_step), 3), round(max(per_step), 3)],
                        "ms_dis_update": round(t_dis, 2), "ms_gen_update": round(t_gen, 2),
                        # host time until the K steps were queued (the HIP queue back-pressures, so this tracks the GPU when it is the
