@@ -240,6 +240,7 @@ int launch_fwd_fast(const ConvGeom& g, FwdFP p, hipStream_t st) {
     p.part = nullptr;
     const int nk = g.K / BK;
     if (p.ring > 0 && (p.act != ACLGAN_ACT_NONE || g.Co % 4 != 0)) splits = 1, p.nkz = nk;   // ring + activation: single pass
+    if (deterministic()) splits = 1, p.nkz = nk;                                             // no partial buffer: the slices would meet in atomics
     if (splits > 1 && p.ring > 0) {
         hipLaunchKernelGGL(ring_zero_kernel, dim3(cdiv(rows * (g.Co / 4), 256)), dim3(256), 0, st, p, rows);
         ACL_CHECK_LAUNCH("ring_zero_kernel");

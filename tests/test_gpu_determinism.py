@@ -34,10 +34,11 @@ def L():
 @pytest.fixture()
 def det(L):
     """deterministic mode for one test; the process-wide switch is restored afterwards"""
+    prev = L.lib.aclgan_get_deterministic()      # (1 when the whole suite runs under ACLGAN_DETERMINISTIC=1)
     L.check(L.lib.aclgan_set_deterministic(1))
     assert L.lib.aclgan_get_deterministic() == 1
     yield
-    L.check(L.lib.aclgan_set_deterministic(0))
+    L.check(L.lib.aclgan_set_deterministic(prev))
 
 
 # (B, Hi, Wi, Ci, Co, k, s, p, up): one per default-mode atomics site
@@ -162,12 +163,13 @@ def test_step_reproducible_bit_for_bit(L, dtype):
     x_a = torch.rand(B, 3, S, S, generator=g) * 2 - 1
     x_b = torch.rand(B, 3, S, S, generator=g) * 2 - 1
     z = [torch.randn(B, 8, 1, 1, generator=g) for _ in range(6)]
+    prev = L.lib.aclgan_get_deterministic()
     try:
         a = _step(T, cfg, nets, x_a, x_b, z, dtype, True)
         b = _step(T, cfg, nets, x_a, x_b, z, dtype, True)
+        ref = _step(T, cfg, nets, x_a, x_b, z, dtype, False)
     finally:
-        L.check(L.lib.aclgan_set_deterministic(0))
-    ref = _step(T, cfg, nets, x_a, x_b, z, dtype, False)
+        L.check(L.lib.aclgan_set_deterministic(prev))
     for which in ("dis", "gen"):
         la, ga = a[which]; lb, gb = b[which]; lr, gr = ref[which]
         assert la and ga

@@ -37,11 +37,12 @@ def test_graph_replay_matches_eager(dtype):
     B, S = 2, 64
     batches = [(torch.rand(B, 3, S, S, generator=g) * 2 - 1, torch.rand(B, 3, S, S, generator=g) * 2 - 1,
                 [torch.randn(B, 8, 1, 1, generator=g) for _ in range(6)]) for _ in range(4)]     # step 1 eager, 2 captures, 3-4 replay
+    prev = L.lib.aclgan_get_deterministic()
     try:
         te, le, pe = _run(T, cfg, nets, batches, compute_dtype=dtype, deterministic=True)
         tg, lg, pg = _run(T, cfg, nets, batches, compute_dtype=dtype, deterministic=True, hip_graph=True)
     finally:
-        L.check(L.lib.aclgan_set_deterministic(0))
+        L.check(L.lib.aclgan_set_deterministic(prev))
     assert tg.hip_graph, "capture fell back to eager execution"
     assert tg._graphs["gen"]["graph"] is not None and tg._graphs["dis"]["graph"] is not None
     assert le == lg, (le, lg)
