@@ -425,6 +425,11 @@ class aclgan_Trainer:
         zz = torch.stack([t.reshape(B, self.style_dim).to(torch.float32) for t in z]).to(self.device).contiguous()
         hpc = hparams_from_config(hp)
         with torch.cuda.device(self.device):
+            det_now = bool(L.lib.aclgan_get_deterministic())
+            if det_now != self.deterministic:      # the process-wide mode changed under us: scratch sizes depend on it
+                self.deterministic = det_now
+                self._ws_shape = None
+                self._graphs = {}
             self._ensure_workspace(B, H, W)
             st = self._st()
             fn = L.lib.aclgan_gen_update if which == "gen" else L.lib.aclgan_dis_update
