@@ -52,33 +52,41 @@ int make_geom(const aclgan_conv_desc* d, ConvGeom* g);
 int conv_fold(const ConvGeom& g, const float* dxp, float* dx, int accumulate, hipStream_t st);
 bool conv_wgrad_fast_supported(const ConvGeom& g);
 // scratch (optional, conv_fwd_scratch_bytes): enables the sub-pixel path of the upsample+5x5 decoder convs
-int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr);
+int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr,
+             float* keepV = nullptr);
+// > 0: conv_fwd (with scratch) runs this layer through Winograd and can leave the input transform V in a caller-owned buffer of this
+// many bytes (keepV); conv_wgrad(.., haveV) of the same layer and input then skips its own input transform.  0: not offered.
+size_t conv_fwd_keep_bytes(const ConvGeom& g);
 // > 0: conv_fwd (with scratch) can emit the normalisation statistics of its output from its epilogue: stats[B][Ho*Wo / chunk][Co] =
 // (mean, M2) of groups of `chunk` output pixels (the return value), the chunk partials norm_fwd combines;  0: not for this shape
 int conv_fwd_stats_chunk(const ConvGeom& g);
 size_t conv_fwd_scratch_bytes(const ConvGeom& g);
 size_t conv_up5_scratch_bytes(const ConvGeom& g);
-int conv_up5_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st);
+int conv_up5_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV = nullptr);
 int conv_fwd_naive(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
 size_t conv_dgrad_scratch_bytes(const ConvGeom& g);
 int conv_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, void* scratch, int accumulate, hipStream_t st);
-int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr);
+int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr, const float* haveV = nullptr);
 size_t conv_wgrad_scratch_bytes(const ConvGeom& g);
 int conv_up5_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);
-int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
+int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, const float* haveV = nullptr);
 
 // tuned kernels (conv_fast.hip); return ACLGAN_EUNSUPPORTED when the shape is not eligible
-int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr);
+int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr,
+                  float* keepV = nullptr);
 size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g);
 int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* dxp, float* dx, int accumulate, bool* direct, hipStream_t st);
 // also accumulates the bias gradient into db when db != nullptr
-int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr);
+int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr, const float* haveV = nullptr);
 size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g);
 
 // Winograd F(4x4,3x3) path of the 3x3 stride-1 reflect-pad-1 layers (conv_wino.hip); EUNSUPPORTED when not eligible / no scratch
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_scratch_bytes(const ConvGeom& g);
-int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats = nullptr);
+int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats = nullptr,
+                  float* keepV = nullptr);
+size_t conv_wino_keep_bytes(const ConvGeom& g);
+size_t conv_up5_wino_keep_bytes(const ConvGeom& g);
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);
 size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g);
 // the four VALID-3x3 phases of the sub-pixel upsample+5x5 path through Winograd (wp: merged fp32 phase filters [4][Co][3][3][Ci])
@@ -86,11 +94,11 @@ bool conv_up5_wino_ok(const ConvGeom& g);
 size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g);
 size_t conv_up5_wino_dgrad_scratch_bytes(const ConvGeom& g);
 size_t conv_up5_wino_wgrad_scratch_bytes(const ConvGeom& g);
-int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st);
+int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV = nullptr);
 int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st);
-int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st);
+int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st, const float* haveV = nullptr);
 size_t conv_up5_dgrad_scratch_bytes(const ConvGeom& g);
-int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
+int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, const float* haveV = nullptr);
 
 // 16-bit MFMA kernels (conv_fast16.hip): operands rounded to bf16 / fp16, fp32 accumulation and outputs.
 // which: 0 forward, 1 dgrad, 2 wgrad.  EUNSUPPORTED when the shape is not eligible.

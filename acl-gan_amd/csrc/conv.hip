@@ -242,13 +242,14 @@ static int launch_fwd(const ConvGeom& g, FwdP p, hipStream_t st) {
 
 size_t conv_fwd_scratch_bytes(const ConvGeom& g) { return conv_fwd_fast_scratch_bytes(g); }
 
-int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch, float* stats) {
+int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch, float* stats, float* keepV) {
+    if (keepV && (!scratch || !conv_fwd_keep_bytes(g))) { set_error("conv_fwd: this layer does not keep a Winograd input transform"); return ACLGAN_EINVAL; }
     if (stats) {      // only offered where conv_fwd_stats_chunk(g) > 0
         if (!scratch || !conv_fwd_stats_chunk(g)) { set_error("conv_fwd: this shape does not emit normalisation statistics"); return ACLGAN_EINVAL; }
-        return conv_fwd_fast(g, x, w, bias, y, st, scratch, stats);
+        return conv_fwd_fast(g, x, w, bias, y, st, scratch, stats, keepV);
     }
     if (scratch) {
-        const int rc = conv_up5_fwd(g, x, w, bias, y, scratch, st);
+        const int rc = conv_up5_fwd(g, x, w, bias, y, scratch, st, keepV);
         if (rc != ACLGAN_EUNSUPPORTED) return rc;
     }
     FwdP p;
@@ -258,9 +259,10 @@ int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bia
     {
         int rc = conv_fwd_small(g, x, w, bias, y, st);
         if (rc != ACLGAN_EUNSUPPORTED) return rc;
-        rc = conv_fwd_fast(g, x, w, bias, y, st, scratch);
+        rc = conv_fwd_fast(g, x, w, bias, y, st, scratch, nullptr, keepV);
         if (rc != ACLGAN_EUNSUPPORTED) return rc;
     }
+    if (keepV) { set_error("conv_fwd: the Winograd path was not taken, nothing kept"); return ACLGAN_EINVAL; }
     if (g.Co > 64) return launch_fwd<2, 2, 2, 2>(g, p, st);   // 128 x 128
     if (g.Co > 32) return launch_fwd<4, 1, 2, 2>(g, p, st);   // 256 x 64
     return launch_fwd<4, 1, 2, 1>(g, p, st);                  // 256 x 32
@@ -753,9 +755,9 @@ size_t conv_wgrad_scratch_bytes(const ConvGeom& g) {
     return (deterministic() && !conv_wgrad_fast_supported(g)) ? std::max(b, wgrad_generic_det_bytes(g)) : b;    // general kernel: slice copies
 }
 
-int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
+int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch, const float* haveV) {
     if (scratch) {
-        const int rc0 = conv_up5_wgrad(g, x, dy, dw, db, scratch, st);
+        const int rc0 = conv_up5_wgrad(g, x, dy, dw, db, scratch, st, haveV);
         if (rc0 != ACLGAN_EUNSUPPORTED) return rc0;
     }
     WgP p;
@@ -766,7 +768,7 @@ int conv_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, fl
     if (rc != ACLGAN_EUNSUPPORTED) return rc;
     rc = ACLGAN_OK;
     if (dw) {
-        rc = conv_wgrad_fast(g, x, dy, dw, db, st, scratch);
+        rc = conv_wgrad_fast(g, x, dy, dw, db, st, scratch, haveV);
         if (rc == ACLGAN_OK) db = nullptr;   // bias gradient fused into the tuned kernel
         if (rc == ACLGAN_EUNSUPPORTED) {
             void* det = nullptr;

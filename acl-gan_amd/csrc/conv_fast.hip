@@ -952,7 +952,7 @@ size_t wgrad_fast_det_bytes(const ConvGeom& g, int Kn, int P, int ny) {
 // ------------------------------------------------------------------------------------------
 
 template <int WM, int WN, int TM, int TN>
-int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, float* wp, hipStream_t st) {
+int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, float* wp, hipStream_t st, float* keepV) {
     const int64_t nm = (int64_t)4 * g.Co * 9 * (g.Ci / 4);
     hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
     ACL_CHECK_LAUNCH("up5_merge_kernel");
@@ -968,7 +968,8 @@ int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bi
     // the phases are VALID 3x3 convolutions: Winograd F(4x4,3x3), all four in one batched GEMM (conv_wino.hip); scratch follows
     // the merged filters and the ring partials
     char* wino_scr = (char*)wp + up5_merged_bytes(g) + ((fwd_partial_bytes(g, 2, BK) + 255) & ~(size_t)255);
-    int rc = conv_up5_wino_ok(g) ? conv_up5_wino_fwd_phases(g, x, wp, bias, y, wino_scr, st) : launch_fwd_fast<WM, WN, TM, TN>(gp, p, st);
+    if (keepV && !conv_up5_wino_ok(g)) { set_error("conv_fwd: this layer does not keep a Winograd input transform"); return ACLGAN_EINVAL; }
+    int rc = conv_up5_wino_ok(g) ? conv_up5_wino_fwd_phases(g, x, wp, bias, y, wino_scr, st, keepV) : launch_fwd_fast<WM, WN, TM, TN>(gp, p, st);
     if (rc) return rc;
     // (2) the output ring of width 2: exact gather (reflection at the borders of the upsampled image)
     p.w = w;
@@ -979,7 +980,7 @@ int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bi
 }
 
 template <int WM, int WN, int TM, int TN>
-int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* dwp, hipStream_t st) {
+int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, float* dwp, hipStream_t st, const float* haveV) {
     // (1) phase weight gradients: valid 3x3 wgrad on the low-res input against the strided views of dy
     const size_t nb = (size_t)4 * g.Co * 9 * g.Ci * sizeof(float);
     hipError_t e = hipMemsetAsync(dwp, 0, nb, st);
@@ -995,7 +996,7 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
     int rc;
     if (kc && conv_up5_wino_wgrad_scratch_bytes(g)) {     // Winograd: the four phase gradients in one batched A^T B GEMM
         void* wino_scr = (char*)dwp + ((wgrad_part_scratch(g, BK, WGKC_TARGET) + 255) & ~(size_t)255);
-        rc = conv_up5_wino_wgrad_phases(g, x, dy, dwp, db, wino_scr, st);
+        rc = conv_up5_wino_wgrad_phases(g, x, dy, dwp, db, wino_scr, st, haveV);
     } else rc = kc ? launch_wgrad_kc_any(g, p, part, st) : launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
     if (rc) return rc;
     // (2) fold the 4 x 3x3 phase gradients back onto the 5x5 filter
@@ -1083,11 +1084,11 @@ size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g) {
     return fwd_partial_bytes(g, 0, BK);
 }
 
-int conv_up5_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st) {
+int conv_up5_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV) {
     if (!fast_enabled() || !up5_eligible(g) || !scratch) return ACLGAN_EUNSUPPORTED;
-    if (g.Co > 64) return up5_fwd_t<2, 2, 2, 2>(g, x, w, bias, y, (float*)scratch, st);
-    if (g.Co > 32) return up5_fwd_t<4, 1, 2, 2>(g, x, w, bias, y, (float*)scratch, st);
-    return up5_fwd_t<4, 1, 2, 1>(g, x, w, bias, y, (float*)scratch, st);
+    if (g.Co > 64) return up5_fwd_t<2, 2, 2, 2>(g, x, w, bias, y, (float*)scratch, st, keepV);
+    if (g.Co > 32) return up5_fwd_t<4, 1, 2, 2>(g, x, w, bias, y, (float*)scratch, st, keepV);
+    return up5_fwd_t<4, 1, 2, 1>(g, x, w, bias, y, (float*)scratch, st, keepV);
 }
 
 // needs conv_up5_scratch_bytes(g) of scratch; dx complete on return (no fold kernel)
@@ -1101,12 +1102,12 @@ int conv_up5_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx
     return up5_dgrad_t<4, 1, 2, 1>(g, dy, w, dx, accumulate, (float*)scratch, st);
 }
 
-int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
+int conv_up5_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, const float* haveV) {
     if (!fast_enabled() || !up5_eligible(g) || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
     if (deterministic() && !wgrad_kc_ok(g)) return ACLGAN_EUNSUPPORTED;    // (the phase / ring launches of the atomics kernel share dw)
-    if (g.Co > 64) return up5_wgrad_t<2, 2, 2, 2>(g, x, dy, dw, db, (float*)scratch, st);
-    if (g.Co > 32) return up5_wgrad_t<2, 2, 1, 2>(g, x, dy, dw, db, (float*)scratch, st);
-    return up5_wgrad_t<1, 4, 1, 2>(g, x, dy, dw, db, (float*)scratch, st);
+    if (g.Co > 64) return up5_wgrad_t<2, 2, 2, 2>(g, x, dy, dw, db, (float*)scratch, st, haveV);
+    if (g.Co > 32) return up5_wgrad_t<2, 2, 1, 2>(g, x, dy, dw, db, (float*)scratch, st, haveV);
+    return up5_wgrad_t<1, 4, 1, 2>(g, x, dy, dw, db, (float*)scratch, st, haveV);
 }
 
 // C_f[T][N] = A_f[T][K] x B_f[N][K]^T for f = 0 .. nslices-1 (fp32, exact MFMA): the tuned forward kernel run as a 1x1 "conv" over a
@@ -1155,10 +1156,19 @@ int conv_fwd_stats_chunk(const ConvGeom& g) {
     if (off < 0) { const char* e = getenv("ACLGAN_NOSTATFUSE"); off = (e && atoi(e)) ? 1 : 0; }
     return (!off && fast_enabled() && g.Ci % 16 == 0 && g.act == ACLGAN_ACT_NONE && conv_wino_ok(g)) ? 16 : 0;
 }
-int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch, float* stats) {
+// bytes of the Winograd input transform conv_fwd can leave behind for conv_wgrad (same path selection as conv_fwd / conv_wgrad)
+size_t conv_fwd_keep_bytes(const ConvGeom& g) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ACLGAN_NOKEEPV"); off = (e && atoi(e)) ? 1 : 0; }
+    if (off || !fast_enabled() || !wgrad_kc_ok(g)) return 0;
+    if (up5_eligible(g)) return conv_up5_wino_wgrad_scratch_bytes(g) ? conv_up5_wino_keep_bytes(g) : 0;
+    if (g.Ci % 16 != 0 || !conv_wino_ok(g) || !conv_wgrad_wino_scratch_bytes(g)) return 0;
+    return conv_wino_keep_bytes(g);
+}
+int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch, float* stats, float* keepV) {
     if (!fast_enabled() || g.Ci % 16 != 0) return ACLGAN_EUNSUPPORTED;
-    if (scratch && conv_wino_ok(g)) return conv_fwd_wino(g, x, w, bias, y, scratch, st, stats);   // 3x3 ResBlock convs: Winograd F(4x4,3x3)
-    if (stats) return ACLGAN_EUNSUPPORTED;
+    if (scratch && conv_wino_ok(g)) return conv_fwd_wino(g, x, w, bias, y, scratch, st, stats, keepV);   // 3x3 ResBlock convs: Winograd F(4x4,3x3)
+    if (stats || keepV) return ACLGAN_EUNSUPPORTED;
     FwdFP p;
     p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
     p.part = (float*)scratch; p.rows = 0;
@@ -1213,7 +1223,7 @@ int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int 
 }
 
 bool conv_wgrad_fast_supported(const ConvGeom& g) { return fast_enabled() && g.Co % 4 == 0 && g.Ci % 4 == 0; }
-int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch) {
+int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch, const float* haveV) {
     if (!fast_enabled() || g.Co % 4 != 0 || g.Ci % 4 != 0) return ACLGAN_EUNSUPPORTED;
     WgFP p;
     p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_dy = 0;
@@ -1221,7 +1231,7 @@ int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* d
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.up = g.up; p.Hu = g.Hu; p.Wu = g.Wu; p.P = g.M; p.Kn = g.K; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
     p.B = g.B; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
-    if (scratch && conv_wino_ok(g) && wgrad_kc_ok(g)) return conv_wgrad_wino(g, x, dy, dw, db, scratch, st);   // 3x3 ResBlock convs: Winograd
+    if (scratch && conv_wino_ok(g) && wgrad_kc_ok(g)) return conv_wgrad_wino(g, x, dy, dw, db, scratch, st, haveV);   // 3x3 ResBlock convs: Winograd
     // with a scratch buffer (always, inside the engine): k-contiguous tiles + ordered slices, reproducible bit for bit;
     // the scratch-less operator call keeps the atomics kernel
     if (wgrad_kc_ok(g) && (scratch || wgrad_part_scratch(g, BK, WGKC_TARGET) == 0)) return launch_wgrad_kc_any(g, p, scratch, st);

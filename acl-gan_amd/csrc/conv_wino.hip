@@ -465,13 +465,14 @@ size_t conv_wino_scratch_bytes(const ConvGeom& g) {
 namespace {
 // filter transform -> input transform -> 36 GEMMs -> output transform.  `in` has Cin_ channels, `out` Cout_.
 int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* w, int w_co, int w_ci, int flip, const float* bias, float* out,
-             int act, int accumulate, int reflect, void* scratch, hipStream_t st, float2* stats = nullptr) {
+             int act, int accumulate, int reflect, void* scratch, hipStream_t st, float2* stats = nullptr, float* keepV = nullptr) {
     const int TY = H / 4, TX = W / 4;
     const int64_t T = (int64_t)B * TY * TX;
     char* cur = (char*)scratch;
     float* U = take(cur, (size_t)36 * Cout_ * Cin_ * 4);
     float* V = take(cur, (size_t)36 * T * Cin_ * 4);
     float* M = take(cur, (size_t)36 * T * Cout_ * 4);
+    if (keepV) V = keepV;         // the caller keeps the input transform for the weight gradient of the same layer
     const WViews vw = one_view(ident_view(H, W));
     hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip);
     ACL_CHECK_LAUNCH("wino_filter_kernel");
@@ -483,9 +484,15 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
 }
 }  // namespace
 // stats (optional): [B][Ho/4 * Wo/4][Co] (mean, M2) pairs of the 4x4 output tiles -- the normalisation layer's chunk partials, for free
-int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats) {
+// keepV (optional, conv_wino_keep_bytes(g) bytes): receives V = B^T x B -- conv_wgrad_wino(.., haveV) of the same layer skips its
+// input transform
+size_t conv_wino_keep_bytes(const ConvGeom& g) {
+    if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
+    return align256((size_t)36 * g.B * (g.Ho / 4) * (g.Wo / 4) * g.Ci * sizeof(float));
+}
+int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats, float* keepV) {
     if (!conv_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
-    return wino_run(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, w, g.Co, g.Ci, 0, bias, y, g.act, 0, 1, scratch, st, (float2*)stats);
+    return wino_run(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, w, g.Co, g.Ci, 0, bias, y, g.act, 0, 1, scratch, st, (float2*)stats, keepV);
 }
 // the INTERIOR of the padded-grid gradient (= dx without the mirrored halo contributions): dx (+)= dy (*) flipped w^T, zero padding
 int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st) {
@@ -500,7 +507,7 @@ size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g) {
     return align256((size_t)36 * T * g.Ci * 4) + align256((size_t)36 * T * g.Co * 4) + align256((size_t)36 * g.Co * g.Ci * 4) +
            align256(WINO_BPART_BYTES + WINO_L2_BYTES) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
 }
-int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
+int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, const float* haveV) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
     if (!wino_bias_ok(g.Co)) return ACLGAN_EUNSUPPORTED;
     const int TY = g.Ho / 4, TX = g.Wo / 4;
@@ -512,7 +519,9 @@ int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* d
     float* bpart = take(cur, WINO_BPART_BYTES + WINO_L2_BYTES);
     void* part = cur;
     const WViews vw = one_view(ident_view(g.Hi, g.Wi));
-    int rc0 = launch_wino_input(x, V, g.B, vw, 1, g.Ci, TY, TX, -1, 1, st);
+    int rc0 = ACLGAN_OK;
+    if (haveV) V = const_cast<float*>(haveV);      // the forward pass of this layer kept its input transform (read-only here)
+    else rc0 = launch_wino_input(x, V, g.B, vw, 1, g.Ci, TY, TX, -1, 1, st);
     if (rc0) return rc0;
     int brows = 0;
     rc0 = launch_wino_outgrad(dy, dM, db ? bpart : (float*)nullptr, g.B, vw, 1, g.Co, TY, TX, st, &brows);
@@ -558,13 +567,18 @@ size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g) {
     const Up5Geo q = up5_geo(g);
     return align256((size_t)144 * g.Co * g.Ci * 4) + align256((size_t)36 * q.T * g.Ci * 4) + align256((size_t)144 * q.T * g.Co * 4) + 256;
 }
-int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st) {
+size_t conv_up5_wino_keep_bytes(const ConvGeom& g) {
+    if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
+    return align256((size_t)36 * up5_geo(g).T * g.Ci * sizeof(float));
+}
+int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV) {
     if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
     float* U = take(cur, (size_t)144 * g.Co * g.Ci * 4);
     float* V = take(cur, (size_t)36 * q.T * g.Ci * 4);
     float* M = take(cur, (size_t)144 * q.T * g.Co * 4);
+    if (keepV) V = keepV;
     hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0);
     ACL_CHECK_LAUNCH("wino_filter_kernel(up5)");
     int rc = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
@@ -604,7 +618,7 @@ size_t conv_up5_wino_wgrad_scratch_bytes(const ConvGeom& g) {
     return align256((size_t)36 * q.T * g.Ci * 4) + align256((size_t)144 * q.T * g.Co * 4) + align256((size_t)144 * g.Co * g.Ci * 4) +
            align256(4 * WINO_BPART_BYTES + WINO_L2_BYTES) + gemm_at_b_slices_scratch((int)q.T, g.Co, g.Ci, 144) + 256;
 }
-int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st) {
+int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st, const float* haveV) {
     if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !wino_bias_ok(g.Co)) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
@@ -613,7 +627,9 @@ int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* d
     float* dU = take(cur, (size_t)144 * g.Co * g.Ci * 4);
     float* bpart = take(cur, 4 * WINO_BPART_BYTES + WINO_L2_BYTES);
     void* part = cur;
-    int rc0 = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
+    int rc0 = ACLGAN_OK;
+    if (haveV) V = const_cast<float*>(haveV);
+    else rc0 = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
     if (rc0) return rc0;
     int brows = 0;
     rc0 = launch_wino_outgrad(dy, dM, db ? bpart : (float*)nullptr, g.B, q.ph, 4, g.Co, q.TY, q.TX, st, &brows);

@@ -297,6 +297,13 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         mean = c.allocf(nstat); rstd = c.allocf(nstat);
         NEED(mean); NEED(rstd);
     }
+    // Winograd layers: the forward's input transform V = B^T x B is exactly what the weight gradient needs again -- keep it (persistent
+    // until the tape has run: 75 MB per ResBlock convolution at 256x256 B=8, ~6 GB per update) instead of recomputing it
+    float* keepV = nullptr;
+    if (train_w && !f16 && !w16) {
+        const size_t kb = conv_fwd_keep_bytes(g);
+        if (kb) { keepV = (float*)c.alloc(kb); NEED(keepV); }
+    }
     const size_t mark = c.top;
     // normalisation statistics from the conv epilogue where the forward kernel offers them (Winograd output transform)
     const int schunk = (ns.kind != ACLGAN_NORM_NONE && !f16) ? conv_fwd_stats_chunk(g) : 0;
@@ -308,7 +315,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         const size_t fb = f16 ? conv_fwd16_scratch_bytes(g) : conv_fwd_scratch_bytes(g);   // merged phase weights (upsample + 5x5 layers), split-K partials
         if (fb) { fscr = c.alloc(fb); NEED(fscr); }
         if (f16) RUN(conv_fwd16(g, dt, in->d, W.w, W.w16, W.b, co->d, fscr, c.st));
-        else RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr, stats));
+        else RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr, stats, keepV));
         c.top = fmark;
     }
     if (ns.kind != ACLGAN_NORM_NONE) {
@@ -341,7 +348,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             const size_t wb = w16 ? conv_wgrad16_scratch_bytes(g) : conv_wgrad_scratch_bytes(g);
             if (wb) { wscr = c.alloc(wb); NEED(wscr); }
             if (w16) RUN(conv_wgrad16(g, dt, in->d, co->g, W.dw, W.db, wscr, c.st));
-            else RUN(conv_wgrad(g, in->d, co->g, W.dw, W.db, c.st, wscr));
+            else RUN(conv_wgrad(g, in->d, co->g, W.dw, W.db, c.st, wscr, keepV));
             c.top = mark;
         }
         if (in->need_grad) {
