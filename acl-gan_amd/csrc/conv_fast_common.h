@@ -230,10 +230,11 @@ __device__ __forceinline__ bool dg_row(const DgFP& p, int m, int ylo, int yhi, i
     r -= top;
     if (r < bot) { const int t = r / p.Wc; y2 = yhi + 1 + t; x2 = r - t * p.Wc; return true; }
     r -= bot;
-    if (r < left) { const int t = r / xlo; y2 = ylo + t; x2 = r - t * xlo; return true; }
+    // side strips COLUMN-major: a 128-row tile then spans one or two x positions instead of all of them, and the halo launches'
+    // per-tile tap list (only the taps some row of the tile needs) shrinks from k*k to ~3k for the 6-wide band of the sub-pixel layers
+    if (r < left) { x2 = r / ny; y2 = ylo + r - x2 * ny; return true; }
     r -= left;
-    const int wr = p.Wc - 1 - xhi;
-    const int t = r / wr; y2 = ylo + t; x2 = xhi + 1 + r - t * wr;
+    const int t = r / ny; x2 = xhi + 1 + t; y2 = ylo + r - t * ny;
     return true;
 }
 
