@@ -223,18 +223,22 @@ __device__ __forceinline__ bool dg_row(const DgFP& p, int m, int ylo, int yhi, i
     }
     const int R = p.Hc * p.Wc - max(ny, 0) * max(nx, 0);
     if (R <= 0 || m >= p.B * R) return false;
-    b = m / R;
-    int r = m - b * R;
+    // STRIP-major over the batch: [all images' top strips][bottom strips][left strips][right strips].  A 128-row tile then lies
+    // inside one strip (except at the three seams), so the per-tile tap list of a halo launch holds the k taps that strip can see
+    // instead of the union over the strips of one image (3x3, pad 1: 3 taps instead of 6-8 -- the tile's k loop is that much shorter).
+    // Side strips are column-major for the same reason (wide bands of the sub-pixel layers: one or two x positions per tile).
     const int top = min(ylo, p.Hc) * p.Wc, bot = min(p.Hc - 1 - yhi, p.Hc - min(ylo, p.Hc)) * p.Wc, left = max(ny, 0) * xlo;
-    if (r < top) { y2 = r / p.Wc; x2 = r - y2 * p.Wc; return true; }
-    r -= top;
-    if (r < bot) { const int t = r / p.Wc; y2 = yhi + 1 + t; x2 = r - t * p.Wc; return true; }
-    r -= bot;
-    // side strips COLUMN-major: a 128-row tile then spans one or two x positions instead of all of them, and the halo launches'
-    // per-tile tap list (only the taps some row of the tile needs) shrinks from k*k to ~3k for the 6-wide band of the sub-pixel layers
-    if (r < left) { x2 = r / ny; y2 = ylo + r - x2 * ny; return true; }
-    r -= left;
-    const int t = r / ny; x2 = xhi + 1 + t; y2 = ylo + r - t * ny;
+    const int right = R - top - bot - left;
+    if (top > 0 && m < p.B * top) { b = m / top; const int r = m - b * top; y2 = r / p.Wc; x2 = r - y2 * p.Wc; return true; }
+    m -= p.B * top;
+    if (bot > 0 && m < p.B * bot) { b = m / bot; const int r = m - b * bot; const int t = r / p.Wc; y2 = yhi + 1 + t; x2 = r - t * p.Wc; return true; }
+    m -= p.B * bot;
+    if (left > 0 && m < p.B * left) { b = m / left; const int r = m - b * left; x2 = r / ny; y2 = ylo + r - x2 * ny; return true; }
+    m -= p.B * left;
+    if (right <= 0) return false;
+    b = m / right;
+    const int r = m - b * right, t = r / ny;
+    x2 = xhi + 1 + t; y2 = ylo + r - t * ny;
     return true;
 }
 
