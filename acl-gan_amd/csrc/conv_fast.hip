@@ -1203,7 +1203,7 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
     return dgrad_fast_all<4, 1, 2, 1>(g, p, dxp, dx, accumulate, direct, st);
 }
 
-// C_f[M][N] += sum_t A_f[t][M] * B_f[t][N] for f = 0 .. nslices-1 (fp32): the ordered-slice weight-gradient kernel run as a 1x1 "conv"
+// C_f[M][N] = sum_t A_f[t][M] * B_f[t][N] for f = 0 .. nslices-1 (fp32): the ordered-slice weight-gradient kernel run as a 1x1 "conv"
 // over a T x 1 "image".  M, N multiples of 64.  part: gemm_at_b_slices_scratch(...) bytes.  Used by the Winograd path.
 size_t gemm_at_b_slices_scratch(int T, int M, int N, int nslices) {
     return wgrad_partial_bytes(wgrad_plan(M, N, N, T, nslices, BK, WGKC_TARGET), M, nslices) + 256;
@@ -1216,6 +1216,7 @@ int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int 
     p.up = 0; p.Hu = T; p.Wu = 1; p.P = T; p.Kn = N; p.chunk = 0; p.tiles_n = 0; p.nwg = 0;
     p.B = 1; p.ring = 0; p.phases = 0; p.Hf = 0; p.Wf = 0;
     p.fsl = nslices; p.fsx_mod = b_mod; p.fs_x = (long long)T * N; p.fs_dy = (long long)T * M;
+    p.dw_overwrite = 1;          // C = A^T B (the slices always go through the ordered partials + finish): no zero-fill of C needed
     ConvGeom g;
     memset(&g, 0, sizeof g);
     g.Co = M; g.Ci = N;

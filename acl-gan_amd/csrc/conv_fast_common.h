@@ -256,6 +256,7 @@ struct WgFP {
     // deterministic mode of the atomics kernel (conv_wgrad_fast_kernel): pixel slice z accumulates into its own zeroed copy
     // dw + z*dw_zs / db + z*db_zs (one writer per element), reduce_slices_ordered adds the copies in order.  0 = shared dw / db.
     long long dw_zs = 0, db_zs = 0;
+    int dw_overwrite = 0;        // ordered-slice launches: wgrad_finish_kernel stores the sum (dw = ...) instead of accumulating (dw += ...)
 };
 
 __device__ __forceinline__ void wg_coord(const WgFP& p, int pix, int& b, int& oy, int& ox) {
@@ -364,7 +365,7 @@ __global__ void wgrad_finish_kernel(WgFP p, WgPartX xp, int BM, int BN, int spli
             s[0] += pt[0]; s[1] += pt[NQ]; s[2] += pt[2 * NQ]; s[3] += pt[3 * NQ];
         }
         f32x4* o = reinterpret_cast<f32x4*>(p.dw + ((size_t)phase * p.Co + m) * p.Kn + n4 * 4);
-        *o += s;
+        if (p.dw_overwrite) *o = s; else *o += s;
     }
     if (p.db)
         for (int m = blockIdx.x * 256 + threadIdx.x; m < p.Co; m += gridDim.x * 256) {

@@ -530,8 +530,6 @@ int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* d
         const int rcb = launch_wino_bias_finish(bpart, brows, g.Co, db, bpart + WINO_BPART_BYTES / sizeof(float), st);
         if (rcb) return rcb;
     }
-    hipError_t e = hipMemsetAsync(dU, 0, (size_t)36 * g.Co * g.Ci * sizeof(float), st);
-    if (e != hipSuccess) return hip_fail(e, "memset dU");
     const int rc = gemm_at_b_slices_f32(dM, V, dU, (int)T, g.Co, g.Ci, 36, 0, part, st);
     if (rc) return rc;
     hipLaunchKernelGGL(wino_filtergrad_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 1), dim3(256), 0, st, dU, dw, g.Co, g.Ci);
@@ -638,8 +636,6 @@ int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* d
         const int rcb = launch_wino_bias_finish(bpart, 4 * brows, g.Co, db, bpart + 4 * WINO_BPART_BYTES / sizeof(float), st);
         if (rcb) return rcb;
     }
-    hipError_t e = hipMemsetAsync(dU, 0, (size_t)144 * g.Co * g.Ci * sizeof(float), st);
-    if (e != hipSuccess) return hip_fail(e, "memset dU");
     const int rc = gemm_at_b_slices_f32(dM, V, dU, (int)q.T, g.Co, g.Ci, 144, 36, part, st);     // V shared by the phases
     if (rc) return rc;
     hipLaunchKernelGGL(wino_filtergrad_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, dU, dwp, g.Co, g.Ci);
