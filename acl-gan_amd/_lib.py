@@ -69,6 +69,8 @@ SYNC_FN = C.CFUNCTYPE(None, vp, vp, ci)
 # every symbol include/aclgan_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "aclgan_version": (ci, []),
+    "aclgan_launch_count": (C.c_longlong, []),
+    "aclgan_gemm_slices_f32": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "aclgan_set_deterministic": (ci, [ci]),
     "aclgan_get_deterministic": (ci, []),
     "aclgan_last_error": (C.c_char_p, []),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "aclgan_workspace_bytes": (ci, [vp, ci, ci, ci, C.POINTER(sz)]),
     "aclgan_bind_workspace": (ci, [vp, vp, sz]),
     "aclgan_forward_workspace_bytes": (ci, [vp, ci, ci, ci, C.POINTER(sz)]),
+    "aclgan_step_algorithmic_bytes": (ci, [vp, ci, ci, ci, ci, C.POINTER(C.c_double)]),
     "aclgan_gen_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
     "aclgan_dis_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
     "aclgan_set_grad_buckets": (ci, [vp, i64, BUCKET_FN, vp]),

@@ -8,6 +8,7 @@
 namespace aclgan {
 
 static thread_local char g_err[512] = "";
+long long g_launches = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -33,12 +34,20 @@ using namespace aclgan;
 
 #include <algorithm>
 
+namespace aclgan { int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, int a_mod, hipStream_t st); }
 extern "C" {
 
 int aclgan_set_deterministic(int on) { set_deterministic(on); return ACLGAN_OK; }
 int aclgan_get_deterministic(void) { return deterministic() ? 1 : 0; }
-int aclgan_version(void) { return 200; }   // 0.2.0: 16-bit MFMA path, gradient buckets
+int aclgan_version(void) { return 300; }   // 0.3.0: 16-bit activation storage, measurement counters
+long long aclgan_launch_count(void) { return g_launches; }
 const char* aclgan_last_error(void) { return g_err; }
+
+// the batched-GEMM launch of the Winograd pipeline alone (the step's dominant kernel): measurement / test support
+int aclgan_gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, void* stream) {
+    ACL_REQUIRE(A && Bm && Cm && nslices >= 1, "null argument");
+    return gemm_slices_f32(A, Bm, Cm, T, K, N, nslices, 0, (hipStream_t)stream);
+}
 
 int aclgan_conv2d_fwd(const aclgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* stream) {
     ConvGeom g;

@@ -11,8 +11,12 @@ namespace aclgan {
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 
+// kernel launches issued by this library since load (measurement support: aclgan_launch_count; bench.py reports launches per step)
+extern long long g_launches;
+
 #define ACL_CHECK_LAUNCH(what)                                           \
     do {                                                                 \
+        ++::aclgan::g_launches;                                          \
         hipError_t e__ = hipGetLastError();                              \
         if (e__ != hipSuccess) return ::aclgan::hip_fail(e__, what);     \
     } while (0)

@@ -24,6 +24,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 
 namespace aclgan {
 
@@ -101,6 +102,11 @@ struct aclgan_ctx {
     aclgan_bucket_fn bucket_fn = nullptr;
     void* bucket_user = nullptr;
     std::vector<int> bucket_order;   // buckets in the order they completed during the last update
+    // ALGORITHMIC HBM bytes of the step being built (aclgan_step_algorithmic_bytes): every operator's inputs read once and
+    // outputs written once at their storage width -- what a perfectly fused-per-operator implementation must move
+    double alg_bytes = 0.0;
+    void count(double bytes) { alg_bytes += bytes; }
+    size_t keep_total = 0;      // bytes of Winograd input transforms kept for the weight gradients of this update (conv_block)
 
     ~aclgan_ctx() { reset_step(); }
     void reset_step() {
@@ -108,6 +114,7 @@ struct aclgan_ctx {
         acts.clear();
         tape.clear();
         top = 0;
+        keep_total = 0;
     }
     void* alloc(size_t bytes) {
         const size_t a = (top + 255) & ~(size_t)255;
@@ -262,6 +269,13 @@ namespace aclgan {
 // graph building blocks.  Every function runs the forward immediately and, when gradients are
 // wanted, pushes one closure on the tape.
 // ------------------------------------------------------------------------------------------
+// arena budget for kept Winograd input transforms (ACLGAN_KEEPV_BUDGET_GB, default 64)
+static size_t keepv_budget() {
+    static size_t v = 0;
+    if (!v) { const char* e = getenv("ACLGAN_KEEPV_BUDGET_GB"); const double gb = e ? atof(e) : 64.0; v = (size_t)(gb * 1073741824.0) + 1; }
+    return v;
+}
+
 struct NormSpec {
     int kind = ACLGAN_NORM_NONE;
     const float* w = nullptr; const float* b = nullptr;   // AdaIN: rows of the MLP output; LN: gamma/beta
@@ -299,11 +313,15 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     }
     // Winograd layers: the forward's input transform V = B^T x B is exactly what the weight gradient needs again -- keep it (persistent
     // until the tape has run: 75 MB per ResBlock convolution at 256x256 B=8, ~6 GB per update) instead of recomputing it
+    // Bounded: the kept transforms of one update may take at most keepv_budget() bytes of the arena (default 64 GB of the 288 GB; 256x256
+    // B=8 needs 6.5 GB, 512x512 B=4 13 GB, B=32 26 GB); beyond it a layer's weight gradient recomputes V (same result bit for bit).
     float* keepV = nullptr;
     if (train_w && !f16 && !w16) {
         const size_t kb = conv_fwd_keep_bytes(g);
-        if (kb) { keepV = (float*)c.alloc(kb); NEED(keepV); }
+        if (kb && c.keep_total + kb <= keepv_budget()) { keepV = (float*)c.alloc(kb); NEED(keepV); c.keep_total += kb; }
     }
+    c.count(4.0 * ((double)in->numel() + (double)Co * g.K + Co + (double)co->numel()));                          // conv: x, w, bias -> y
+    if (ns.kind != ACLGAN_NORM_NONE) c.count(4.0 * (2.0 * (double)co->numel() + (residual ? (double)co->numel() : 0.0)));   // norm+act(+residual): y -> out
     const size_t mark = c.top;
     // normalisation statistics from the conv epilogue where the forward kernel offers them (Winograd output transform)
     const int schunk = (ns.kind != ACLGAN_NORM_NONE && !f16) ? conv_fwd_stats_chunk(g) : 0;
@@ -331,6 +349,10 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     c.push([=]() -> int {
         aclgan_ctx& c = *cp;
         if (!out->gw) return ACLGAN_OK;   // no gradient reached this block
+        // backward of norm / activation: x (or y), dy -> dx (+ dres); wgrad: x, dy -> dw, db; dgrad: dy, w -> dx
+        c.count(4.0 * (3.0 * (double)co->numel() + ((residual && residual->need_grad) ? (double)co->numel() : 0.0)));
+        if (train_w) c.count(4.0 * ((double)in->numel() + (double)co->numel() + (double)Co * g.K + Co));
+        if (in->need_grad) c.count(4.0 * ((double)co->numel() + (double)Co * g.K + (double)in->numel()));
         if (ns.kind != ACLGAN_NORM_NONE) {
             const size_t mark = c.top;
             void* scr = c.alloc(norm_scratch_bytes(g.B, HW, Co));
@@ -398,6 +420,7 @@ static int dense(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int O, int a
     NEED(out->d); if (want) NEED(out->g);
     if (!W.w) { set_error("dense: parameters not bound"); return ACLGAN_EINVAL; }
     RUN(linear_fwd(B, I, O, in->d, W.w, W.b, act, out->d, c.st));
+    c.count(4.0 * ((double)B * I + (double)O * I + O + (double)B * O) * (want ? 3.0 : 1.0));    // (+ backward: the same operands again, twice)
     *out_p = out;
     if (!want) return ACLGAN_OK;
     aclgan_ctx* cp = &c;
@@ -446,6 +469,7 @@ static int style_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
     Act* p = c.new_act(h->B, 1, 1, d, want);
     NEED(p->d); if (want) NEED(p->g);
     RUN(gap_fwd(h->B, h->H * h->W, d, h->d, p->d, c.st));
+    c.count(4.0 * (double)h->numel() * (want ? 2.0 : 1.0));
     if (want) {
         aclgan_ctx* cp = &c;
         Act* hh = h;
@@ -532,6 +556,7 @@ static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<A
             Act* p = c.new_act(src->B, (src->H - 1) / 2 + 1, (src->W - 1) / 2 + 1, src->C, src->need_grad);
             NEED(p->d); if (p->need_grad) NEED(p->g);
             RUN(avgpool3s2_fwd(src->B, src->H, src->W, src->C, src->d, p->d, c.st));
+            c.count(4.0 * ((double)src->numel() + (double)p->numel()) * (src->need_grad ? 2.0 : 1.0));
             if (src->need_grad) {
                 aclgan_ctx* cp = &c;
                 c.push([=]() -> int {
@@ -586,6 +611,7 @@ static int blend(aclgan_ctx& c, Act* dec4, Act* bg, Act* pair_first, Act** out_p
         }
     }
     RUN(focus_blend_fwd(dec4->B, dec4->H * dec4->W, dec4->d, bg->d, out->d, pair_first ? pair_first->d : nullptr, pair ? pair->d : nullptr, c.st));
+    c.count(4.0 * (double)dec4->B * dec4->H * dec4->W * (4 + 3 + 3 + (pair_first ? 9 : 0)) * (want ? 2.0 : 1.0));
     *out_p = out;
     if (pair_p) *pair_p = pair;
     if (!want) return ACLGAN_OK;
@@ -769,6 +795,7 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     float* ftot = nullptr;
     if (c.sync_fn) { ftot = c.allocf(8); NEED(ftot); }
     for (int i = 0; i < 3; ++i) RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, hp.focus_upper, sums + (size_t)i * nfs, c.st));
+    c.count(4.0 * (double)npix * (3 * 2 + 2 * (4 + 3 + 4)));     // focus masks read + gradient written; L1: decoder output, image, gradient
     if (ftot) {
         RUN(focus_totals(sums, npix, 3, ftot, c.st));
         if (!c.dry) c.sync_fn(c.sync_user, ftot, 6);
@@ -940,6 +967,26 @@ int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out) {
         if (pk > best) best = pk;
     }
     *out = best + 4096;
+    return ACLGAN_OK;
+}
+int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int W, double* out) {
+    ACL_REQUIRE(ctx && out && (which == 0 || which == 1), "bad argument");
+    aclgan_ctx& c = *ctx;
+    ACL_REQUIRE(c.groups[0].param && c.groups[1].param, "bind parameters first");
+    aclgan_hparams hp;
+    memset(&hp, 0, sizeof hp);
+    hp.focus_loss = 1.f; hp.alpha = 1.f;
+    c.reset_step();
+    c.dry = true; c.peak = 0; c.trained = which; c.alg_bytes = 0.0;
+    const aclgan_bucket_fn keep = c.bucket_fn;
+    c.bucket_fn = nullptr;
+    const int rc = which == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)
+                              : dis_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr);
+    c.bucket_fn = keep;
+    c.dry = false; c.trained = -1;
+    c.reset_step();
+    if (rc) return rc;
+    *out = c.alg_bytes + (4.0 + 28.0) * (double)c.groups[which].numel;    // + zero_grad + Adam (p, g, m, v read; p, m, v written)
     return ACLGAN_OK;
 }
 // workspace of ONE forward-only call (aclgan_gen_encode / aclgan_gen_decode / aclgan_dis_forward) at this image shape:

@@ -162,6 +162,7 @@ __global__ void adam_scaled_kernel(float* __restrict__ p, const float* __restric
     }
 }
 __global__ void scale_update_kernel(float* state, int group) {
+    state[7] = state[0];      // the scale the gradient buffers of THIS update carry (readable after the scale has moved on)
     if (state[3] != 0.f) {
         state[0] = fmaxf(state[0] * 0.5f, 1.f); state[2] = 0.f; state[4 + group] += 1.f;
     } else {

@@ -197,19 +197,36 @@ class GpuImageLoader:
     """DataLoader(dataset, batch_size, shuffle=train, drop_last=True, num_workers) counterpart: iterating yields
     device batches.  `.dataset[i]` returns the transformed sample i as a [3,H,W] device tensor (train.py:44-47)."""
 
-    def __init__(self, dataset, batch_size, train, new_size, height, width, num_workers=4, crop=True, device="cuda"):
+    def __init__(self, dataset, batch_size, train, new_size, height, width, num_workers=4, crop=True, device="cuda", rank=0, world_size=1,
+                 shard_seed=0):
+        """rank / world_size (data parallel, not in the reference): batch_size is PER RANK; every epoch all ranks draw the SAME
+        permutation (generator seeded shard_seed + epoch) and rank r takes slice r of each global batch of world_size * batch_size
+        samples -- disjoint shards, every sample at most once per epoch, equal batch counts on all ranks."""
         self.source, self.batch_size, self.train = dataset, batch_size, train
+        self.rank, self.world, self.shard_seed, self._epoch = int(rank), max(1, int(world_size)), int(shard_seed), 0
+        assert 0 <= self.rank < self.world
         self.transform = GpuBatchTransform(new_size, height, width, train, crop, device)
         self.pool = ThreadPoolExecutor(max_workers=max(1, num_workers))
         self.dataset = _TransformedView(self)
 
     def __len__(self):
-        return len(self.source) // self.batch_size          # drop_last=True
+        return len(self.source) // (self.batch_size * self.world)          # drop_last=True
+
+    def batch_indices(self):
+        """the sample indices of this rank's batches for the next epoch (advances the epoch counter)"""
+        n = len(self.source)
+        if not self.train:
+            order = list(range(n))
+        elif self.world == 1:
+            order = torch.randperm(n).tolist()          # the default generator, like DataLoader(shuffle=True)
+        else:
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(self.shard_seed + self._epoch)).tolist()
+        self._epoch += 1
+        gb = self.batch_size * self.world
+        return [order[b * gb + self.rank * self.batch_size: b * gb + (self.rank + 1) * self.batch_size] for b in range(len(self))]
 
     def __iter__(self):
-        n = len(self.source)
-        order = torch.randperm(n).tolist() if self.train else list(range(n))
-        batches = [order[b * self.batch_size:(b + 1) * self.batch_size] for b in range(len(self))]
+        batches = self.batch_indices()
         nxt = self._decode(batches[0]) if batches else None
         for b in range(len(batches)):
             cur = nxt
@@ -232,19 +249,19 @@ class _TransformedView:
 
 
 def get_data_loader_folder(input_folder, batch_size, train, new_size=None, height=256, width=256, num_workers=4, crop=True,
-                           datakind='', device="cuda"):
+                           datakind='', device="cuda", rank=0, world_size=1):
     """utils.py:91-100"""
-    return GpuImageLoader(ImageFolder(input_folder), batch_size, train, new_size, height, width, num_workers, crop, device)
+    return GpuImageLoader(ImageFolder(input_folder), batch_size, train, new_size, height, width, num_workers, crop, device, rank, world_size)
 
 
 def get_data_loader_list(root, file_list, batch_size, train, new_size=None, height=256, width=256, num_workers=4, crop=True,
-                         datakind='', device="cuda"):
+                         datakind='', device="cuda", rank=0, world_size=1):
     """utils.py:78-89"""
-    return GpuImageLoader(ImageFilelist(root, file_list), batch_size, train, new_size, height, width, num_workers, crop, device)
+    return GpuImageLoader(ImageFilelist(root, file_list), batch_size, train, new_size, height, width, num_workers, crop, device, rank, world_size)
 
 
-def get_all_data_loaders(conf, device="cuda"):
-    """utils.py:43-76: (train_a, train_b, test_a, test_b)"""
+def get_all_data_loaders(conf, device="cuda", rank=0, world_size=1):
+    """utils.py:43-76: (train_a, train_b, test_a, test_b); rank / world_size shard the TRAIN loaders (see GpuImageLoader)"""
     batch_size, num_workers = conf['batch_size'], conf['num_workers']
     if 'new_size' in conf:
         new_size_a = new_size_b = conf['new_size']
@@ -254,10 +271,12 @@ def get_all_data_loaders(conf, device="cuda"):
     datakind = conf.get('data_kind', '')
     if 'data_root' in conf:
         r = conf['data_root']
-        mk = lambda sub, train, ns, h, w: get_data_loader_folder(os.path.join(r, sub), batch_size, train, ns, h, w, num_workers, True, datakind, device)
+        mk = lambda sub, train, ns, h, w: get_data_loader_folder(os.path.join(r, sub), batch_size, train, ns, h, w, num_workers, True, datakind, device,
+                                                                 rank if train else 0, world_size if train else 1)
         return (mk('trainA', True, new_size_a, height, width), mk('trainB', True, new_size_b, height, width),
                 mk('testA', False, new_size_a, new_size_a, new_size_a), mk('testB', False, new_size_b, new_size_b, new_size_b))
-    mk = lambda f, l, train, ns, h, w: get_data_loader_list(conf[f], conf[l], batch_size, train, ns, h, w, num_workers, True, datakind, device)
+    mk = lambda f, l, train, ns, h, w: get_data_loader_list(conf[f], conf[l], batch_size, train, ns, h, w, num_workers, True, datakind, device,
+                                                            rank if train else 0, world_size if train else 1)
     return (mk('data_folder_train_a', 'data_list_train_a', True, new_size_a, height, width),
             mk('data_folder_train_b', 'data_list_train_b', True, new_size_b, height, width),
             mk('data_folder_test_a', 'data_list_test_a', False, new_size_a, new_size_a, new_size_a),

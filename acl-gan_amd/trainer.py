@@ -394,8 +394,13 @@ class aclgan_Trainer:
         return {"scale": v[0], "clean_updates": int(v[2]), "skipped_gen": int(v[4]), "skipped_dis": int(v[5])}
 
     def grad_scale(self):
-        """the factor the gradient buffers carry (fp16: the loss scale of the LAST update; else 1)"""
-        return 1.0 if self._lscale is None else float(self._lscale[0])
+        """the factor the gradient buffers carry: fp16 -- before the first update the initial loss scale, afterwards the scale the
+        LAST update ran with (slot 7 of the device state, recorded by aclgan_adam_step before it halves / doubles the live scale);
+        fp32 / bf16 -- 1"""
+        if self._lscale is None:
+            return 1.0
+        v = self._lscale.cpu().tolist()
+        return float(v[7]) if v[7] > 0 else float(v[0])
 
     def _draw_z(self, B):
         # three draws from the CPU generator, in the reference's order (trainer.py:99-101); data-parallel ranks use
@@ -495,6 +500,7 @@ class aclgan_Trainer:
         bucket's all-reduce starts while the rest of the backward is still running (ddp.BucketReducer).
         z noise: every rank draws its own shard's z from a generator seeded with initial_seed() + rank."""
         self._reducer = None
+        self._exposed_events, self._exposed_ms = [], 0.0
         world = self._dist_world()
         if not world:
             return
@@ -509,6 +515,12 @@ class aclgan_Trainer:
         self._zgen = torch.Generator().manual_seed(torch.initial_seed() + dist.get_rank())
         if os.environ.get("ACLGAN_DDP_OVERLAP", "1") != "0":
             self._reducer = BucketReducer(self._ctx, lambda g: self._grad[g], world)
+        if self.hip_graph:
+            # HIP-graph replay is single-GPU only: the bucket callbacks and the forward sync point are host code that starts
+            # collectives from inside the update, which a captured graph cannot replay -- say so instead of silently ignoring the option
+            import warnings
+            warnings.warn("aclgan_Trainer: hip_graph=True is ignored in data-parallel runs (world size %d): updates run eagerly" % world)
+            self.hip_graph = False
         # optional: the reference's global-batch semantics of the focus losses (config key ddp_global_focus / env
         # ACLGAN_DDP_GLOBAL_FOCUS=1): the 6 mask sums are all-reduced at a forward sync point of gen_update
         if self._hp.get("ddp_global_focus", False) or os.environ.get("ACLGAN_DDP_GLOBAL_FOCUS") == "1":
@@ -530,11 +542,29 @@ class aclgan_Trainer:
         world = self._dist_world()
         if not world:
             return
+        # GPU-side exposure of the exchange: the compute stream does nothing between these two events except wait for the
+        # collectives, so their distance is the part of the all-reduce that was NOT hidden behind the backward
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
         if self._reducer is not None:
             self._reducer.finish(grp)
-            return
-        from .ddp import allreduce_flat
-        allreduce_flat(self._grad[grp], world)
+        else:
+            from .ddp import allreduce_flat
+            allreduce_flat(self._grad[grp], world)
+        ev[1].record()
+        self._exposed_events.append(ev)
+        if len(self._exposed_events) > 4096:
+            self.allreduce_exposed_ms()
+
+    def allreduce_exposed_ms(self, reset=True):
+        """total milliseconds the compute stream spent waiting for gradient collectives since the last call (synchronises)"""
+        torch.cuda.synchronize(self.device)
+        self._exposed_ms += sum(a.elapsed_time(b) for a, b in self._exposed_events)
+        self._exposed_events = []
+        v = self._exposed_ms
+        if reset:
+            self._exposed_ms = 0.0
+        return v
 
     # ---- the hot path (trainer.py:90-170, 247-293) ----
     def gen_update(self, x_a, x_b, hyperparameters, z=None):
@@ -632,7 +662,13 @@ class aclgan_Trainer:
         cpu = lambda sd: OrderedDict((k, v.cpu()) for k, v in sd.items())  # noqa: E731
         torch.save({"AB": cpu(self.gen_AB.state_dict()), "BA": cpu(self.gen_BA.state_dict())}, gen_name)
         torch.save({"A": cpu(self.dis_A.state_dict()), "B": cpu(self.dis_B.state_dict()), "2": cpu(self.dis_2.state_dict())}, dis_name)
-        torch.save({"gen": self._opt_state_dict(L.GROUP_GEN), "dis": self._opt_state_dict(L.GROUP_DIS)}, opt_name)
+        opt = {"gen": self._opt_state_dict(L.GROUP_GEN), "dis": self._opt_state_dict(L.GROUP_DIS)}
+        if self._lscale is not None:
+            # fp16 only (an extra key the reference's loader ignores: trainer.py:313-316 reads 'gen' / 'dis'): the dynamic loss-scale state --
+            # live scale, clean-update counter and the SKIPPED-update counts Adam's bias-correction step excludes.  Adam's per-tensor
+            # 'step' above counts applied + skipped updates (the reference's own counter semantics: one per optimizer.step() call).
+            opt["aclgan_loss_scale_state"] = self._lscale.cpu().clone()
+        torch.save(opt, opt_name)
 
     @staticmethod
     def _get_model_list(dirname, key):   # utils.py:211-220
@@ -652,10 +688,14 @@ class aclgan_Trainer:
         self.dis_A.load_state_dict(sd["A"]); self.dis_B.load_state_dict(sd["B"]); self.dis_2.load_state_dict(sd["2"])
         sd = torch.load(os.path.join(checkpoint_dir, "optimizer.pt"), map_location="cpu")
         self._load_opt_state_dict(L.GROUP_DIS, sd["dis"]); self._load_opt_state_dict(L.GROUP_GEN, sd["gen"])
-        # get_scheduler(..., iterations) (trainer.py:318-320, utils.py:263-271): StepLR(last_epoch=iterations) steps once
-        # in its constructor, so the reference resumes at last_epoch = iterations + 1 and (torch 1.2.0, the pinned
-        # version: closed-form get_lr) lr = lr0 * gamma ** ((iterations + 1) // step_size).  Mirrored.
-        self._sched_calls = iterations + 1
+        if self._lscale is not None and "aclgan_loss_scale_state" in sd:      # fp16: resume the loss scale and the skipped-update counts
+            self._lscale.copy_(sd["aclgan_loss_scale_state"].to(self.device, torch.float32))
+        # get_scheduler(..., iterations) (trainer.py:318-320, utils.py:263-271) builds StepLR(last_epoch=iterations).  The reference
+        # pins torch 1.2.0 (acl-gan.yaml), whose _LRScheduler.__init__ ends with self.step(last_epoch): the scheduler resumes AT
+        # last_epoch = iterations and (closed-form get_lr of that version) lr = lr0 * gamma ** (iterations // step_size).  torch >= 1.4
+        # calls self.step() instead and would resume one epoch later (iterations + 1) -- the pinned version is the one mirrored here
+        # (ACLGAN_RESUME_SCHED_PLUS1=1 selects the torch >= 1.4 behaviour).
+        self._sched_calls = iterations + (1 if os.environ.get("ACLGAN_RESUME_SCHED_PLUS1") == "1" else 0)
         self._hp = hyperparameters
         self._setup_data_parallel()
         print("Resume from iteration %d" % iterations)

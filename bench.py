@@ -48,10 +48,31 @@ PEAK = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}   # TFLOP/s dense matrix 
 CPU_THREADS_CAP = 32   # oneDNN/ATen on the GPU box's 256 hardware threads thrashes on B=1 tensors
 
 
-def male2female_config():
+def load_config(path=None):
     import yaml
-    with open(os.path.join(ROOT, "configs", "male2female.yaml")) as f:
+    with open(path or os.path.join(ROOT, "configs", "male2female.yaml")) as f:
         return yaml.safe_load(f)
+
+
+def male2female_config():
+    return load_config()
+
+
+# per-GPU batch of the BASELINE.json configuration each shipped YAML stands for (configs[1] / [2] / [3]; configs[4] = male2female fp16: 32)
+BASELINE_BATCH = {"male2female": 8, "selfie2anime": 8, "glasses_removal": 4}
+
+
+def step_traffic(dtype, S, B):
+    """memory-side bytes of ONE step from the committed PMC passes (rocprofv3 --pmc cannot run inside the timed process):
+    profiles/r03_step_traffic.json, written by scripts/step_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    runs of scripts/probe_step.py = sum over every kernel of one dis_update + gen_update of 2 x FETCH_SIZE (gfx950 correction,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_step_traffic.json")) as f:
+            ent = json.load(f).get("%s_%d_b%d" % (dtype, S, B))
+        return (ent["bytes_per_step"], "profiles/r03_step_traffic.json:%s_%d_b%d" % (dtype, S, B)) if ent else (None, None)
+    except Exception:   # noqa: BLE001
+        return None, None
 
 
 RESBLOCK_GMAC_256 = 637.8     # of which the 3x3 ResBlock convs: 120 forward + 72 dgrad + 72 wgrad launches x 2.4159 GMAC
@@ -121,8 +142,10 @@ def cpu_baseline(timeout_s=200):
 
 
 def dominant_kernel_probe(L, dtype, reps=20):
-    """conv_fwd on the ResBlock shape (B=8, 64x64, 256->256, 3x3): the kernel family that carries
-    ~97% of the step's FLOPs.  Timed with HIP events on the launch stream."""
+    """The step's dominant kernel on the ResBlock shape (B=8, 64x64, 256->256, 3x3), timed with HIP events on the launch stream.
+    fp32: the 36 batched GEMM slices of the Winograd F(4x4,3x3) pipeline (conv_fwd_fast_kernel<2,2,1,2,4>, 20 % of the step) -- the launch
+    ALONE through aclgan_gemm_slices_f32: frac = the FLOPs that launch issues / time / 157.3; the four-launch convolution it belongs to is
+    reported beside it (`pipeline_*`: algorithmic = direct-convolution FLOPs).  bf16 / fp16: conv_fwd16 (one launch = the convolution)."""
     import ctypes as C
     B, H, Cc = 8, 64, 256
     flop_direct = 2.0 * (B * H * H) * Cc * (9 * Cc)
@@ -132,45 +155,47 @@ def dominant_kernel_probe(L, dtype, reps=20):
     y = torch.empty(B, H, H, Cc, device="cuda")
     d = L.ConvDesc(B, H, H, Cc, Cc, 3, 1, 1, 0, 0)
     st = L.stream_ptr()
+
+    def timed(call):
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     if dtype == "fp32":
+        wino = os.environ.get("ACLGAN_NOWINO", "0") in ("", "0")
         nb = L.lib.aclgan_conv2d_fwd_scratch_bytes(C.byref(d))
         scr = torch.empty(nb // 4 + 64, device="cuda")
-        # the ResBlock convolution as the step runs it (with scratch): Winograd F(4x4,3x3) = filter / input transform, 36 batched
-        # GEMMs on conv_fwd_fast_kernel<2,2,1,2,4> (64 x 128 tiles), output transform.  achieved = ALGORITHMIC (direct-convolution) FLOPs / time.
-        call = lambda: L.check(L.lib.aclgan_conv2d_fwd_ws(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(scr), st))   # noqa: E731
-        name = "ResBlock conv 8x64x64x256->256 3x3 forward (Winograd F(4x4,3x3): 4 launches, GEMMs on conv_fwd_fast_kernel<2,2,1,2,4>)"
-        # algorithmic bytes = input + weights + output; HBM-side traffic of the Winograd pipeline adds the V / M planes (2 x 75 MB
-        # written and read once each, mostly served by the 256 MB Infinity Cache) -- not re-measured with PMC this round
-        wino = os.environ.get("ACLGAN_NOWINO", "0") in ("", "0")
-        # memory-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside the timed
-        # process): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, summed over the four launches of the pipeline
-        extra = {"traffic": 469.0e6 if wino else 240.6e6, "algorithmic_bytes": 69.5e6,
-                 "traffic_source": "profiles/r02_hbm_traffic_winograd.txt" if wino else "profiles/r01_hbm_traffic_conv_fwd.txt",
-                 "executed_flop_per_launch": flop_direct * 0.25 if wino else flop_direct}
-    else:
-        code = L.DTYPE[dtype]
-        w16 = torch.empty(w.numel(), dtype=torch.int16, device="cuda")
-        L.check(L.lib.aclgan_pack_weights16(L.ptr(w), L.ptr(w16), None, Cc, 9, Cc, code, st))
-        call = lambda: L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), code, L.ptr(x), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), None, st))   # noqa: E731
-        name = "conv_fwd16_kernel<%s> 8x64x64x256->256 3x3 (ResBlock conv)" % dtype
-        extra = {"traffic": None, "algorithmic_bytes": 69.5e6 - w.numel() * 2}
-    for _ in range(3):
-        call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    flop = 2.0 * (B * H * H) * Cc * (9 * Cc)
-    out = {"name": name, "ms": round(ms, 4), "flop_per_launch": flop, "achieved": round(flop / ms / 1e9, 2), "unit": "TFLOP/s",
-           "frac": round(flop / ms / 1e9 / PEAK[dtype], 4)}
-    out.update(extra)
-    if "executed_flop_per_launch" in out:   # the MACs really issued (Winograd: 1/4): the hardware-utilisation figure of this kernel
-        out["executed_achieved"] = round(out["executed_flop_per_launch"] / ms / 1e9, 2)
-        out["executed_frac"] = round(out["executed_flop_per_launch"] / ms / 1e9 / PEAK[dtype], 4)
-    return out
+        ms_pipe = timed(lambda: L.check(L.lib.aclgan_conv2d_fwd_ws(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(scr), st)))
+        T = B * (H // 4) * (H // 4)
+        V = torch.randn(36, T, Cc, device="cuda"); U = torch.randn(36, Cc, Cc, device="cuda") * 0.02; M = torch.empty(36, T, Cc, device="cuda")
+        ms = timed(lambda: L.check(L.lib.aclgan_gemm_slices_f32(L.ptr(V), L.ptr(U), L.ptr(M), T, Cc, Cc, 36, st)))
+        flop = 2.0 * 36 * T * Cc * Cc                      # = 1/4 of the direct convolution's FLOPs
+        # memory-side bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE of this launch)
+        out = {"name": "conv_fwd_fast_kernel<2,2,1,2,4>: 36 Winograd GEMM slices [2048 x 256] x [256 x 256] (ResBlock conv 8x64x64x256->256 3x3)",
+               "ms": round(ms, 4), "flop_per_launch": flop, "achieved": round(flop / ms / 1e9, 2), "unit": "TFLOP/s",
+               "frac": round(flop / ms / 1e9 / PEAK[dtype], 4),
+               "algorithmic_bytes": 4.0 * (36 * T * Cc * 2 + 36 * Cc * Cc), "traffic": 226.9e6,
+               "traffic_source": "profiles/r02_hbm_traffic_winograd.txt (GEMM launch: 2 x 75.7 MB fetched + 75.5 MB written)",
+               "pipeline": "filter transform + input transform + this launch + output transform = one ResBlock convolution forward",
+               "pipeline_ms": round(ms_pipe, 4), "pipeline_algorithmic_flop": flop_direct,
+               "pipeline_algorithmic_achieved": round(flop_direct / ms_pipe / 1e9, 2),
+               "pipeline_algorithmic_frac": round(flop_direct / ms_pipe / 1e9 / PEAK[dtype], 4),
+               "pipeline_frac": round((flop if wino else flop_direct) / ms_pipe / 1e9 / PEAK[dtype], 4),
+               "pipeline_traffic": 469.0e6 if wino else 240.6e6, "pipeline_algorithmic_bytes": 69.5e6}
+        return out
+    code = L.DTYPE[dtype]
+    w16 = torch.empty(w.numel(), dtype=torch.int16, device="cuda")
+    L.check(L.lib.aclgan_pack_weights16(L.ptr(w), L.ptr(w16), None, Cc, 9, Cc, code, st))
+    ms = timed(lambda: L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), code, L.ptr(x), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), None, st)))
+    return {"name": "conv_fwd16_kernel<%s> 8x64x64x256->256 3x3 (ResBlock conv, fp32 activations in HBM)" % dtype, "ms": round(ms, 4),
+            "flop_per_launch": flop_direct, "achieved": round(flop_direct / ms / 1e9, 2), "unit": "TFLOP/s",
+            "frac": round(flop_direct / ms / 1e9 / PEAK[dtype], 4), "traffic": None, "algorithmic_bytes": 69.5e6 - w.numel() * 2}
 
 
 def spawn_ranks(args):
@@ -193,9 +218,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch; default: 8 (BASELINE configs[1], [2]), 32 with --dtype fp16 (configs[4]: 256 over 8 GPUs)")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="compute dtype of the heavy convolutions")
+    ap.add_argument("--config", type=str, default=None, help="YAML under configs/ naming the workload (default configs/male2female.yaml = BASELINE configs[1]; "
+                    "selfie2anime.yaml = configs[2], glasses_removal.yaml = configs[3]): architecture, hyper-parameters, image size and compute_dtype come from it")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch; default: the BASELINE batch of the config (8 / 8 / 4), 32 with --dtype fp16 (configs[4]: 256 over 8 GPUs)")
+    ap.add_argument("--size", type=int, default=None, help="image size; default: the config's crop_image_height")
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default=None, help="compute dtype of the heavy convolutions; default: the config's compute_dtype (fp32)")
+    ap.add_argument("--ddp-overlap", type=int, choices=[0, 1], default=None, help="N > 1: 1 (default) = gradient buckets all-reduced from inside the backward; "
+                    "0 = plain bucketed all-reduce after the backward (fallback if the overlapped path misbehaves on a new RCCL / topology)")
     ap.add_argument("--deterministic", action="store_true", help="ordered reductions everywhere (bit-reproducible step); default: the fast plan")
     ap.add_argument("--graph", action="store_true", help="replay each update from a captured HIP graph (launch-bound regimes: small batches / images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,8 +235,19 @@ def main():
         cpu_baseline_worker()
         return
 
+    cfg_path = args.config or os.path.join(ROOT, "configs", "male2female.yaml")
+    cfg = load_config(cfg_path)
+    cfg_name = os.path.splitext(os.path.basename(cfg_path))[0]
+    if args.dtype is None:
+        args.dtype = str(cfg.get("compute_dtype", "fp32"))
+    if args.size is None:
+        args.size = int(cfg.get("crop_image_height", 256))
     if args.batch is None:
-        args.batch = 32 if args.dtype == "fp16" else 8
+        args.batch = 32 if (args.dtype == "fp16" and cfg_name == "male2female") else BASELINE_BATCH.get(cfg_name, int(cfg.get("batch_size", 8)))
+    if args.ddp_overlap is not None:
+        os.environ["ACLGAN_DDP_OVERLAP"] = str(args.ddp_overlap)
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")    # a failed / hung collective tears the job down instead of hanging the bench
+    os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "1")
     t_start = time.perf_counter()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -240,7 +280,6 @@ def main():
     from aclgan_amd import _lib as L
     from aclgan_amd.trainer import aclgan_Trainer
 
-    cfg = male2female_config()
     cfg["display_size"] = 1
     torch.manual_seed(0)       # (replicas are made identical by the trainer's rank-0 broadcast, not by this seed)
     tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, deterministic=True if args.deterministic else None,
@@ -269,23 +308,31 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    launches0 = L.lib.aclgan_launch_count()
+    tr.allreduce_exposed_ms()      # reset
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(args.steps):
         step()
         evs[i + 1].record()
     t_enq = time.perf_counter() - t0      # every launch of the K steps is queued here; the GPU is still working
+    launches_per_step = (L.lib.aclgan_launch_count() - launches0) / float(args.steps)
+    exposed_ms = 0.0
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    exposed_ms = tr.allreduce_exposed_ms() / args.steps      # compute-stream time spent waiting for gradient collectives, per step
     per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     ev_ms = sum(per_step)
     if use_dist:
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        te = torch.tensor([exposed_ms], device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        exposed_ms = float(te.item())
     losses_ok = all(map(lambda n: torch.isfinite(getattr(tr, n)).item(), ["loss_gen_total", "loss_dis_total"]))
     replicas_identical = None
     if use_dist:      # (outside the timed region) data-parallel replicas must still hold identical parameters after K steps
@@ -330,35 +377,58 @@ def main():
         step_s = ev_ms / args.steps / 1e3
         ach = tflop_img * B / step_s      # per GPU, from HIP events on the launch stream
         peak = PEAK[args.dtype]
-        name = {"fp32": "male2female", "bf16": "selfie2anime (male2female architecture)", "fp16": "male2female"}[args.dtype]
+        name = cfg_name if (args.config or args.dtype == "fp32") else {"bf16": "selfie2anime (male2female architecture)", "fp16": "male2female"}[args.dtype]
+        # memory side of the step: algorithmic bytes from a dry run of the scheduler (every operator's inputs read once, outputs written
+        # once), measured bytes from the committed PMC passes
+        import ctypes as C
+        alg_bytes = 0.0
+        for which in (0, 1):
+            v = C.c_double()
+            L.check(L.lib.aclgan_step_algorithmic_bytes(tr._ctx, which, B, S, S, C.byref(v)), "step_algorithmic_bytes")
+            alg_bytes += v.value
+        traffic, traffic_src = step_traffic(args.dtype, S, B)
+        ex_ach = tflop_exec * B / step_s
         out = {
             "metric": "training images/sec at 256x256 (gen+dis step)" if S == 256 else "training images/sec at %dx%d (gen+dis step)" % (S, S),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic U(-1,1) A/B batches, reference init statistics, seeded z",
             "config": {"workload": "%s %dx%d %s, batch=%d per GPU: dis_update + gen_update (fwd+bwd+Adam each)" % (name, S, S, args.dtype, B),
+                       "config_file": os.path.relpath(cfg_path, ROOT),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "rccl_world_size": dist.get_world_size() if use_dist else 1,
                        "dist_backend": dist.get_backend() if use_dist else None, "replicas_identical": replicas_identical,
                        "grad_allreduce": ("overlapped with backward (bucket callback)" if getattr(tr, "_reducer", None) is not None else
                                           ("after backward" if use_dist else "none (1 GPU)")),
+                       # compute-stream time per step spent WAITING for the gradient exchange (events around finish() of the bucket reducer /
+                       # the post-backward all-reduce), max over ranks: what of the all-reduce was NOT hidden behind the backward
+                       "ms_allreduce_exposed": round(exposed_ms, 3) if use_dist else None,
                        "deterministic": bool(tr.deterministic), "hip_graph": bool(tr.hip_graph and tr._graphs.get("gen", {}).get("graph") is not None),
                        "losses_finite": bool(losses_ok), "ms_per_step_median": round(statistics.median(per_step), 3),
                        "ms_per_step_min_max": [round(min(per_step), 3), round(max(per_step), 3)],
                        "ms_dis_update": round(t_dis, 2), "ms_gen_update": round(t_gen, 2),
                        # host time until the K steps were queued (the HIP queue back-pressures, so this tracks the GPU when it is the
-                       # bottleneck) and the launch-bound floor: the whole step on 64x64 B=1 images, i.e. ~2000 tiny launches (what a HIP graph could approach)
+                       # bottleneck) and the launch-bound floor: the whole step on 64x64 B=1 images, i.e. the same launches with next to no work
                        "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 2),
+                       "kernel_launches_per_step": round(launches_per_step, 1),
                        "launch_bound_floor_ms_per_step": None if launch_floor_ms is None else round(launch_floor_ms, 2),
                        "reference_cadence_D1_G2_images_per_s": round(world * B / ((t_dis + 0.5 * t_gen) / 1e3), 2)},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None,
-                         "flop_per_launch": tflop_img * B * 1e12, "launch": "one dis_update+gen_update step (per GPU)",
+            # frac = what the MFMA pipes really issue (EXECUTED FLOPs: Winograd F(4x4,3x3) runs the 3x3 convolutions with 1/4 of the
+            # direct-convolution MACs, the sub-pixel path the upsample+5x5 layers with 9/25) over the dense matrix peak: a hardware
+            # fraction, never above 1.  algorithmic_* = the SURVEY 8d contract figure (direct-convolution FLOPs of the step): it can
+            # exceed 1 exactly because of those two algebraic reductions.
+            "roofline": {"bound": "mfma", "achieved": round(ex_ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ex_ach / peak, 4),
+                         "flop_per_launch": tflop_exec * B * 1e12, "launch": "one dis_update+gen_update step (per GPU)",
                          "event_ms_per_step": round(ev_ms / args.steps, 3),
-                         "executed_flop_per_launch": tflop_exec * B * 1e12, "executed_achieved": round(tflop_exec * B / step_s, 2),
-                         "executed_frac": round(tflop_exec * B / step_s / peak, 4),
-                         "note": ("achieved/frac = ALGORITHMIC work (SURVEY 8d: direct-convolution FLOPs of the step) over the dense MFMA peak; "
-                                  "the fp32 path runs the 3x3 ResBlock convolutions and the sub-pixel phases with Winograd F(4x4,3x3) "
-                                  "(1/4 of their MACs), so frac can exceed 1 -- executed_* is what the MFMA pipes really issue")},
+                         "algorithmic_flop_per_launch": tflop_img * B * 1e12, "algorithmic_achieved": round(ach, 2),
+                         "algorithmic_frac": round(ach / peak, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
+                         "traffic_ratio": None if not traffic else round(traffic / alg_bytes, 2),
+                         "hbm_floor_ms": round(alg_bytes / 8e12 * 1e3, 2),
+                         "note": ("frac = EXECUTED FLOPs / time / dense MFMA peak (hardware utilisation); algorithmic_frac = SURVEY 8d contract FLOPs "
+                                  "(direct convolution, 2.623 TFLOP per image at 256x256) / time / peak -- above frac because Winograd F(4x4,3x3) and the "
+                                  "sub-pixel decomposition execute fewer MACs than the contract counts; traffic = 2 x FETCH_SIZE + WRITE_SIZE summed over "
+                                  "one step (committed PMC passes), algorithmic_bytes = every operator's inputs + outputs once")},
         }
         if args.dtype != "fp32":
             out["config"]["precision"] = ("heavy convolutions: %s operands on v_mfma_f32_32x32x16, fp32 accumulate; fp32 master weights, "

@@ -112,6 +112,12 @@ typedef struct aclgan_ctx aclgan_ctx;
 
 /* ---- library ---- */
 int aclgan_version(void);
+/* kernels launched by the library since it was loaded (measurement support: launches per step on the bench line) */
+long long aclgan_launch_count(void);
+/* C[f][T][N] = A[f][T][K] x B[f][N][K]^T for f < nslices, fp32 MFMA: the batched-GEMM launch the Winograd F(4x4,3x3) pipeline of the
+ * 3x3 convolutions (networks.py:297-310) spends its MFMA time in, exposed alone so that bench.py can time the step's dominant
+ * kernel with HIP events and tests can check it against torch.bmm.  K % 16 == 0. */
+int aclgan_gemm_slices_f32(const float* A, const float* B, float* C, int T, int K, int N, int nslices, void* stream);
 const char* aclgan_last_error(void);
 /* Deterministic mode (process-wide; also ACLGAN_DETERMINISTIC=1; the counterpart of torch.use_deterministic_algorithms, which the
  * reference never turns on -- its cuDNN backward is not reproducible either, train.py:29 sets cudnn.benchmark = True).
@@ -150,7 +156,7 @@ int aclgan_set_compute_dtype(aclgan_ctx* ctx, int dtype);
 int aclgan_bind_params16(aclgan_ctx* ctx, int group, void* w16, void* w16t);
 /* fp16 dynamic loss scaling.  state: device float[8], caller-owned, zero-initialised except state[0]:
  *   [0] scale S  [1] 1/S  [2] consecutive overflow-free updates  [3] overflow flag of the update in flight
- *   [4],[5] updates skipped so far (gen, dis)  [6] growth interval (0: 2000)  [7] reserved
+ *   [4],[5] updates skipped so far (gen, dis)  [6] growth interval (0: 2000)  [7] the scale the LAST update's gradient buffers carry (written by aclgan_adam_step before it moves [0])
  * Every loss-gradient seed is multiplied by S; aclgan_adam_step first scans the group's gradients, and -- all on the
  * device, no host round trip -- either applies Adam with g/S or skips the update, halves S and counts the skip (the
  * bias-correction step excludes skipped updates); S doubles after `growth interval` clean updates.  The gradient
@@ -164,6 +170,12 @@ int aclgan_bind_workspace(aclgan_ctx* ctx, void* workspace, size_t bytes);
  * test.py:55-131 and trainer.sample need -- far smaller than a training step's, and without its shape constraints
  * (any H, W the networks accept, e.g. the 256x340 a Resize(256) of a non-square photo yields) */
 int aclgan_forward_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out);
+/* ALGORITHMIC HBM bytes of one update at this batch shape (measurement support, SURVEY.md 8d / bench.py roofline.traffic):
+ * every operator of the step (trainer.py:99-169 / 254-292: convolutions, norms, activations, blends, losses and their
+ * backward) counted with its inputs read once and its outputs written once at their storage width, from a launch-free dry
+ * run of the same scheduler; zero_grad (4 B / parameter) and Adam (28 B / parameter, trainer.py:170,293) included.
+ * which: 0 gen_update, 1 dis_update. */
+int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int W, double* out);
 
 /* ---- the hot path ---- */
 /* aclgan_Trainer.gen_update minus zero_grad/opt.step (trainer.py:92-169): forward of the whole

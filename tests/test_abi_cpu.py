@@ -88,3 +88,29 @@ def test_product_path_refuses_to_run_without_gpu():
     cfg = O.default_config(); cfg["dis"]["gan_type"] = "nsgan"
     with pytest.raises(trainer.L.AclganError):
         trainer.arch_from_config(cfg)
+
+
+def test_step_algorithmic_bytes_dry_run_without_gpu():
+    """aclgan_step_algorithmic_bytes (bench.py roofline.algorithmic_bytes) is a launch-free dry run of the step scheduler: host logic.
+    Conv / norm / loss traffic scales with B*H*W exactly; the parameter traffic (weights read per pass, zero_grad, Adam) does not."""
+    import torch
+    L = _lib()
+    a = L.Arch(3, 6, 64, 256, 8, 4, 2, 4, 64, 4, 3)
+    ctx = C.c_void_p()
+    L.check(L.lib.aclgan_ctx_create(C.byref(a), C.byref(ctx)))
+    t = torch.zeros(8)
+    for grp in (0, 1):
+        L.check(L.lib.aclgan_bind_params(ctx, grp, L.ptr(t), L.ptr(t), None, None))
+
+    def q(which, B, S):
+        v = C.c_double()
+        L.check(L.lib.aclgan_step_algorithmic_bytes(ctx, which, B, S, S, C.byref(v)))
+        return v.value
+    g8, d8, g16, g8_512 = q(0, 8, 256), q(1, 8, 256), q(0, 16, 256), q(0, 8, 512)
+    assert 40e9 < g8 < 90e9 and 10e9 < d8 < 30e9            # ~60 GB + ~19 GB per step at 256x256 B=8 (fp32 storage): ~10 ms at 8 TB/s
+    fixed = 2 * g8 - g16                                     # what does not scale with the batch: parameter traffic
+    assert 0 < fixed < 0.1 * g8
+    assert abs((g8_512 - fixed) - 4 * (g8 - fixed)) <= 1e-4 * g8_512      # (the MLP and the style vectors scale with B only)
+    assert L.lib.aclgan_step_algorithmic_bytes(ctx, 2, 8, 256, 256, C.byref(C.c_double())) != 0
+    assert L.lib.aclgan_launch_count() == 0                  # a dry run launches nothing
+    L.lib.aclgan_ctx_destroy(ctx)

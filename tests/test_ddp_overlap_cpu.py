@@ -132,10 +132,43 @@ def _worker(rank, world, port, ret):
     L.lib.aclgan_ctx_destroy(ctx)
 
 
-def test_bucket_reducer_gloo_world2():
-    world = 2
-    port = 31500 + (os.getpid() % 2000)
+def _run_world(world, port_base):
+    port = port_base + (os.getpid() % 2000)
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_bucket_reducer_gloo_world2():
+    _run_world(2, 31500)
+
+
+def test_bucket_reducer_gloo_world8():
+    """the driver's 8-GPU shape: 8 ranks, the same dry-run scheduler on each, identical bucket order on all 8 (the collectives
+    match up), every bucket reduced exactly once, the result is the 8-rank average"""
+    _run_world(8, 34500)
+
+
+def test_loader_shards_are_disjoint_and_equal_sized(tmp_path):
+    """torchrun train.py: the per-rank loader shards (acl-gan_amd/data.py GpuImageLoader rank / world_size): one shared permutation
+    per epoch, rank r takes slice r of every global batch -- disjoint, equal batch counts, a new permutation every epoch"""
+    sys.path.insert(0, ROOT)
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd.data import GpuImageLoader
+    src = list(range(103))
+    world, bs = 4, 3
+    loaders = [GpuImageLoader(src, bs, True, 64, 64, 64, num_workers=1, device="cpu", rank=r, world_size=world, shard_seed=7) for r in range(world)]
+    assert all(len(l) == 103 // (bs * world) for l in loaders)
+    for epoch in range(2):
+        per_rank = [l.batch_indices() for l in loaders]
+        assert all(len(b) == len(loaders[0]) and all(len(x) == bs for x in b) for b in per_rank)
+        flat = [i for b in per_rank for x in b for i in x]
+        assert len(flat) == len(set(flat)) == len(loaders[0]) * bs * world        # disjoint shards, nobody sees a sample twice
+        if epoch == 0:
+            first = flat
+        else:
+            assert flat != first                                                  # reshuffled
+    # world 1 keeps the reference behaviour (default generator permutation, batch_size samples per batch)
+    one = GpuImageLoader(src, bs, True, 64, 64, 64, num_workers=1, device="cpu")
+    assert len(one) == 103 // bs and len(one.batch_indices()) == 103 // bs

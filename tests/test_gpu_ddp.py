@@ -94,3 +94,209 @@ def test_bench_two_ranks_share_one_gpu():
     assert out["config"]["grad_allreduce"].startswith("overlapped") and out["config"]["dist_backend"] == "gloo"
     assert out["config"]["replicas_identical"] is True and out["config"]["losses_finite"] is True
     assert r.stdout.strip().splitlines()[-1].startswith("{")      # the JSON line is the last line of stdout
+
+
+def _bench_shared(args, timeout=900):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.update(ACLGAN_DIST_BACKEND="gloo", ACLGAN_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ACLGAN_BENCH_FORCE_DIST", "ACLGAN_DDP_OVERLAP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.strip().splitlines()[-1].startswith("{")
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_eight_ranks_control_flow_and_overlap_fallback():
+    """the driver's `bench.py --gpus 8` control flow on the 1-GPU box (8 ranks share GPU 0 over gloo, reduced width so that eight
+    replicas fit comfortably): self-spawn, broadcast, 8 shards, bucket callbacks on every rank, max-over-ranks timing, one JSON
+    line; and the --ddp-overlap 0 fallback (plain bucketed all-reduce after the backward) at 2 ranks."""
+    out = _bench_shared(["--gpus", "8", "--steps", "2", "--warmup", "1", "--size", "64", "--batch", "1", "--no-cpu-baseline", "--no-launch-floor"])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 and out["config"]["rccl_world_size"] == 8
+    assert out["config"]["grad_allreduce"].startswith("overlapped")
+    assert out["config"]["replicas_identical"] is True and out["config"]["losses_finite"] is True
+    assert out["config"]["ms_allreduce_exposed"] is not None and out["config"]["ms_allreduce_exposed"] >= 0.0
+    assert out["roofline"]["frac"] <= 1.0
+    out = _bench_shared(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--batch", "2", "--no-cpu-baseline", "--no-launch-floor",
+                         "--ddp-overlap", "0"])
+    assert out["config"]["grad_allreduce"] == "after backward" and out["config"]["replicas_identical"] is True
+
+
+def test_bucket_callback_fires_after_the_last_writer():
+    """What the overlapped all-reduce relies on: when the engine calls back for a bucket, every kernel that writes that bucket has
+    already been ENQUEUED -- a consumer ordered after the compute stream at callback time (ProcessGroupNCCL: the RCCL stream waits
+    for an event recorded on the current stream when all_reduce(async_op=True) is called) reads the bucket's FINAL values.  Checked
+    without a second GPU: the callback is replaced by exactly that ordering -- event on the compute stream, side stream waits for
+    it, side stream snapshots the bucket -- while the backward keeps running; the gradient buffer is poisoned before the update.
+    After the update every snapshot must equal the final buffer bit for bit."""
+    import ctypes as C
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd import _lib as L
+    from aclgan_amd.trainer import aclgan_Trainer
+    from oracle import aclgan_oracle as O
+    cfg = O.default_config()
+    cfg["gen"].update(dim=16, mlp_dim=32, n_res=2); cfg["dis"].update(dim=16); cfg["display_size"] = 1
+    g = torch.Generator().manual_seed(41)
+    x_a = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    x_b = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    z = [torch.randn(2, 8, 1, 1, generator=g) for _ in range(3)]
+    tr = aclgan_Trainer(cfg)
+    side = torch.cuda.Stream()
+    BUCKET = 32768
+    fired = {"grp": None, "order": []}
+    snap = {}
+
+    def on_bucket(user, group, bucket, offset, numel):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            snap[group][offset: offset + numel].copy_(tr._grad[group][offset: offset + numel], non_blocking=True)
+        fired["order"].append(int(bucket))
+
+    cb = L.BUCKET_FN(on_bucket)
+    L.check(L.lib.aclgan_set_grad_buckets(tr._ctx, BUCKET, cb, None), "set_grad_buckets")
+    try:
+        for which, grp in (("dis", 1), ("gen", 0)):
+            snap[grp] = torch.full_like(tr._grad[grp], float("nan"))
+            tr._grad[grp].fill_(float("nan"))            # poison: zero_grad + every writer must have run before a bucket is read
+            fired["order"] = []
+            (tr.dis_update if which == "dis" else tr.gen_update)(x_a, x_b, cfg, z=z)
+            torch.cuda.synchronize()
+            nb = (tr._grad[grp].numel() + BUCKET - 1) // BUCKET
+            assert sorted(fired["order"]) == list(range(nb)), (which, len(fired["order"]), nb)
+            assert torch.isfinite(tr._grad[grp]).all()
+            assert torch.equal(snap[grp], tr._grad[grp]), (which, int((snap[grp] != tr._grad[grp]).sum()))
+    finally:
+        L.lib.aclgan_set_grad_buckets(tr._ctx, 0, C.cast(None, L.BUCKET_FN), None)
+
+
+def _shard_trainers(cfg, nets, n):
+    from aclgan_amd.trainer import aclgan_Trainer
+    from oracle import aclgan_oracle as O
+    trs = [aclgan_Trainer(cfg) for _ in range(n)]
+    for tr in trs:
+        for name in O.OracleTrainer.NETS:
+            getattr(tr, name).load_state_dict(nets[name], strict=False)
+    return trs
+
+
+@pytest.mark.parametrize("global_focus", [True, False])
+def test_shard_equivalence_on_one_gpu(global_focus):
+    """SURVEY.md 8e's correctness statement for the data-parallel step, checked without a second GPU: one trainer on a batch of 4
+    versus two trainers on its halves whose gradient buffers are averaged by hand (what the RCCL AVG all-reduce does).
+    dis_update is linear in the batch: equal.  gen_update: equal when the focus 'size' loss sees the GLOBAL mask sums
+    (ddp_global_focus: the forward sync point is fed the sum of both shards' totals, exactly what the 6-float all-reduce produces);
+    without it (standard DDP semantics) everything the size loss reaches through the masks differs and nothing else does -- the
+    hyper-parameters are chosen so that the size term is ACTIVE (relu(sum(m - upper)) > 0), otherwise the test would be vacuous."""
+    import ctypes as C
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd import _lib as L
+    from oracle import aclgan_oracle as O
+    cfg = O.default_config()
+    cfg["gen"].update(dim=16, mlp_dim=32, n_res=2); cfg["dis"].update(dim=16); cfg["display_size"] = 1
+    cfg["focus_epsilon"] = 0.5        # smooth digit term
+    cfg["focus_upper"] = 0.45         # masks sit around 0.5 at init: sum(m - 0.45) > 0 -> the size loss and its gradient are non-zero
+    nets = O.test_nets(cfg, 3)
+    g = torch.Generator().manual_seed(43)
+    x_a = torch.rand(4, 3, 128, 128, generator=g) * 2 - 1
+    x_b = torch.rand(4, 3, 128, 128, generator=g) * 2 - 1
+    z = [torch.randn(4, 8, 1, 1, generator=g) for _ in range(6)]
+    full, s0, s1 = _shard_trainers(cfg, nets, 3)
+    shards = (s0, s1)
+
+    def sl(t, r):
+        return t[2 * r: 2 * r + 2]
+
+    # ---- dis_update: averaged shard gradients == full-batch gradients ----
+    full.dis_update(x_a, x_b, cfg, z=z[:3])
+    for r, tr in enumerate(shards):
+        tr.dis_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[:3]])
+    torch.cuda.synchronize()
+    avg = 0.5 * (s0._grad[1] + s1._grad[1])
+    err = ((avg - full._grad[1]).double().norm() / full._grad[1].double().norm()).item()
+    print("shard equivalence, dis_update: relative L2 of the averaged gradient buffer %.2e" % err)
+    assert err <= 1e-4, err
+    assert abs(0.5 * (float(s0.loss_dis_total) + float(s1.loss_dis_total)) - float(full.loss_dis_total)) <= 1e-5 * abs(float(full.loss_dis_total))
+
+    # ---- gen_update ----
+    full.gen_update(x_a, x_b, cfg, z=z[3:])
+    assert float(full.loss_gen_focus_A_size) > 0 or float(full.loss_gen_focus_B_size) > 0, "fixture: the size term must be active"
+    cbs = []
+    if global_focus:
+        # pass 1: capture each shard's 6 local totals at its forward sync point; pass 2: feed every shard the SUM (= all-reduce SUM)
+        local = {}
+        mode = {"write": None}
+
+        def make(rank, tr):
+            def on_sync(user, ptr, n):
+                off = int(ptr) - tr._ws.data_ptr()
+                t = tr._ws[off: off + 4 * n].view(torch.float32)
+                if mode["write"] is None:
+                    local[rank] = t.clone()
+                else:
+                    t.copy_(mode["write"])
+            return L.SYNC_FN(on_sync)
+        for r, tr in enumerate(shards):
+            cb = make(r, tr); cbs.append(cb)
+            L.check(L.lib.aclgan_set_forward_sync(tr._ctx, cb, None, 2), "set_forward_sync")
+            p0 = tr._param[0].clone(); m0 = tr._m[0].clone(); v0 = tr._v[0].clone(); st0 = tr._opt[0]["steps"]
+            tr.gen_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[3:]])
+            torch.cuda.synchronize()
+            tr._param[0].copy_(p0); tr._m[0].copy_(m0); tr._v[0].copy_(v0); tr._opt[0]["steps"] = st0      # undo pass 1's Adam step
+        mode["write"] = local[0] + local[1]
+    for r, tr in enumerate(shards):
+        tr.gen_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[3:]])
+    torch.cuda.synchronize()
+    for tr in shards:
+        L.lib.aclgan_set_forward_sync(tr._ctx, C.cast(None, L.SYNC_FN), None, 1)
+    avg = 0.5 * (s0._grad[0] + s1._grad[0])
+    ref = full._grad[0]
+    err = ((avg - ref).double().norm() / ref.double().norm()).item()
+    print("shard equivalence, gen_update (global focus sums: %s): relative L2 of the averaged gradient buffer %.2e" % (global_focus, err))
+    if global_focus:
+        assert err <= 1e-4, err
+        for n in ("loss_gen_focus_A_size", "loss_gen_focus_B_size", "loss_gen_focus_A2_size", "loss_gen_total"):      # global-batch values on every rank
+            assert abs(float(getattr(s0, n)) - float(getattr(full, n))) <= 1e-4 * max(1e-6, abs(float(getattr(full, n)))), n
+    else:
+        # per-rank size loss (standard DDP semantics): delta * relu(T_r)^2 / (H W b 3) on each half instead of delta * relu(T_0 + T_1)^2 /
+        # (H W 2b 3) on the whole batch.  With T_0 ~ T_1 the full-batch VALUE is ~2x the mean of the shard values while the GRADIENTS
+        # nearly coincide (2 T / 2b vs 2 T_r / b): the difference is the imbalance T_r - T / 2 between the shards' masks
+        fs, ss = float(full.loss_gen_focus_A_size), 0.5 * (float(s0.loss_gen_focus_A_size) + float(s1.loss_gen_focus_A_size))
+        assert 1.5 * ss < fs < 2.5 * ss, (fs, ss)
+        assert err <= 5e-2, err
+        # everything that is linear in the batch still agrees: the reported batch-mean losses average exactly
+        for n in ("loss_gen_adv_A", "loss_gen_adv_B", "loss_gen_adv_2", "loss_idt_A", "loss_idt_B", "loss_gen_focus_A_digit"):
+            want = float(getattr(full, n))
+            got = 0.5 * (float(getattr(s0, n)) + float(getattr(s1, n)))
+            assert abs(got - want) <= 2e-5 * max(1e-6, abs(want)), (n, got, want)
+
+
+def test_train_py_two_ranks_share_one_gpu(tmp_path):
+    """`torchrun train.py` end to end on the 1-GPU box (two ranks on GPU 0 over gloo): init_process_group, LOCAL_RANK device binding,
+    rank-0-only directories / config copy / log lines / checkpoint, lockstep steps, clean exit on both ranks."""
+    import subprocess
+    import sys
+    import yaml
+    from conftest import ROOT
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "male2female.yaml")))
+    cfg["gen"].update(dim=8, mlp_dim=16, n_res=1); cfg["dis"].update(dim=8)
+    cfg.update(batch_size=1, crop_image_height=64, crop_image_width=64, new_size=64, display_size=1, snapshot_save_iter=2, log_iter=1)
+    cpath = os.path.join(tmp_path, "tiny.yaml")
+    yaml.safe_dump(cfg, open(cpath, "w"))
+    env = dict(os.environ)
+    env.update(ACLGAN_DIST_BACKEND="gloo", ACLGAN_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ACLGAN_BENCH_FORCE_DIST", "ACLGAN_DDP_OVERLAP"):
+        env.pop(k, None)
+    port = 23000 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "train.py"), "--config", cpath, "--output_path", str(tmp_path),
+                        "--synthetic", "--max_iter", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    ck = os.path.join(tmp_path, "outputs", "tiny", "checkpoints")
+    assert sorted(os.listdir(ck)) == ["dis_00000002.pt", "dis_00000003.pt", "gen_00000002.pt", "gen_00000003.pt", "optimizer.pt"]
+    assert r.stdout.count("Iteration: 00000001/") == 1 and r.stdout.count("Finish training") == 1      # rank 0 alone prints

@@ -123,6 +123,29 @@ def test_forward_and_losses_512_b4(T):
     _forward_and_losses(T, 4, 512)
 
 
+def _host_mem_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 0.0
+
+
+def _fit_batch(B, S):
+    """the oracle's autograd graph of one update holds ~3.2 GB per 256x256 sample in host memory; shrink B to what
+    the box has (never needed on the 1.5 TB GPU boxes; protects small hosts from being driven out of memory)"""
+    per = 3.5 * (S / 256.0) ** 2
+    avail = _host_mem_gb()
+    while B > 1 and avail and B * per + 16 > avail:
+        B //= 2
+    return B
+
+
+FLOOR = 1e-3         # tensors whose reference gradient norm is below FLOOR * (largest gradient norm of the update) are reported separately
+
+
 def _step_gradients(T, B, S):
     cfg = O.default_config()
     cfg["display_size"] = 1
@@ -136,17 +159,26 @@ def _step_gradients(T, B, S):
     for n, v in list(od.losses.items()) + list(og.losses.items()):
         got = float(getattr(trd if n.startswith("loss_dis") else trg, n))
         assert abs(got - v) <= (5e-3 if n.endswith("_size") else LTOL) * max(1e-3, abs(v)), (n, got, v)
-    worst = []
+    # every tensor: PURE relative L2 error against its own reference norm.  Tensors whose reference norm is below FLOOR x the
+    # update's largest gradient norm are listed by name and held to the same absolute error a FLOOR-sized tensor would be allowed.
+    worst, small = [], []
     for tr, orc, nets_ in ((trd, od, ("dis_A", "dis_B", "dis_2")), (trg, og, ("gen_AB", "gen_BA"))):
         gmax = max(float(t.grad.norm()) for n in nets_ for t in orc.nets[n].values())
         for n in nets_:
             for k, gr in getattr(tr, n).named_grads():
                 ref = orc.nets[n][k].grad.double()
                 err = (gr.cpu().double() - ref).norm().item()
-                worst.append((err / (ref.norm().item() + 1e-5 * gmax / GTOL), n, k))
-    worst.sort(reverse=True)
-    print("worst gradient tensors @%dx%d B=%d (relative L2):" % (S, S, B), [("%.2e" % e, n, k) for e, n, k in worst[:6]])
+                rn = ref.norm().item()
+                if rn >= FLOOR * gmax:
+                    worst.append((err / rn, n, k))
+                else:
+                    small.append((err / (FLOOR * gmax), rn / gmax, n, k))
+    worst.sort(reverse=True); small.sort(reverse=True)
+    print("worst gradient tensors @%dx%d B=%d (relative L2, %d tensors):" % (S, S, B, len(worst)), [("%.2e" % e, n, k) for e, n, k in worst[:6]])
+    print("tensors under the floor (|g_ref| < %.0e x largest; error relative to the floor, own norm relative to the largest): %d" % (FLOOR, len(small)),
+          [("%.2e" % e, "%.1e" % r, n, k) for e, r, n, k in small[:8]])
     assert worst[0][0] <= GTOL, worst[:6]
+    assert not small or small[0][0] <= GTOL, small[:6]
 
 
 def test_step_gradients_256_b2(T):
@@ -155,3 +187,14 @@ def test_step_gradients_256_b2(T):
 
 def test_step_gradients_512_b1(T):
     _step_gradients(T, 1, 512)
+
+
+def test_step_gradients_256_b8(T):
+    """gradients AT THE BENCHMARKED BATCH (BASELINE configs[1]): the weight-gradient split plans (ordered pixel slices, Winograd
+    A^T B with K = 2048 tiles) differ from the B=2 case above"""
+    _step_gradients(T, _fit_batch(8, 256), 256)
+
+
+def test_step_gradients_512_b4(T):
+    """BASELINE configs[3] at its batch"""
+    _step_gradients(T, _fit_batch(4, 512), 512)

@@ -320,3 +320,15 @@ def test_reference_lsgan_conventions_on_hip(L, opv):
     assert abs(total([(of, 0.0), (orr, 1.0)]) - float(opv["lsgan_dis_loss"])) <= 1e-4 * float(opv["lsgan_dis_loss"])      # fake -> 0, real -> 1
     assert abs(total([(of, 1.0)]) - float(opv["lsgan_gen_loss"])) <= 1e-4 * float(opv["lsgan_gen_loss"])                    # fake -> 1
     assert abs(total([(of, 1.0), (orr, 0.0)]) - float(opv["lsgan_gen_d2_loss"])) <= 1e-4 * float(opv["lsgan_gen_d2_loss"])  # pair_A1 -> 1, pair_A2 -> 0
+
+
+@pytest.mark.parametrize("T_,K,N,ns", [(2048, 256, 256, 36), (200, 64, 48, 5), (961, 128, 64, 144)])
+def test_gemm_slices_f32_vs_bmm(L, T_, K, N, ns):
+    """aclgan_gemm_slices_f32 (the Winograd pipeline's batched-GEMM launch, exported for bench.py's dominant-kernel probe):
+    C[f] = A[f] B[f]^T against a float64 bmm; ragged row / column tiles included."""
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(ns, T_, K, generator=g).cuda(); Bm = torch.randn(ns, N, K, generator=g).cuda()
+    Cm = torch.full((ns, T_, N), float("nan"), device="cuda")
+    L.check(L.lib.aclgan_gemm_slices_f32(L.ptr(A), L.ptr(Bm), L.ptr(Cm), T_, K, N, ns, L.stream_ptr()), "gemm_slices_f32")
+    ref = torch.bmm(A.double(), Bm.double().transpose(1, 2))
+    assert ((Cm.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6

@@ -113,6 +113,11 @@ def test_forward_matches_reference(T, fix):
         chk("dis_2_pA2_s%d" % s, d2[s])
 
 
+# per-tensor relative L2 of the HIP gradients against the fp32 oracle at 64x64, B <= 2 (measured worst, final round-3 build, recorded
+# in profiles/r03_gpu_tests.log): one ReLU mask flip moves an upstream tensor by ~1 / sqrt(#elements of the layer)
+ETOL_SMOOTH, ETOL_DEFAULT = 6e-2, 1.5e-1
+
+
 def _grads_by_name(tr, nets):
     out = {}
     for n in nets:
@@ -160,14 +165,16 @@ def test_update_steps_match_reference(T, fix, ltol, gtol):
     # CPU oracle itself sits 1e-3..3e-2 from the fp64 reference on these fixtures, and every HIP
     # backward kernel alone is exact to ~1e-7 on the same data (tests/test_gpu_ops.py,
     # scripts/diag_tail.py).
-    # The bound is NOT tight on purpose: the forward is not bit-reproducible run to run (late discriminator layers and
-    # the ring of the sub-pixel path combine split-K partials with fp32 atomics), so WHICH pre-activations flip differs
-    # between runs; single tensors were seen anywhere in 2e-3..2.8e-2 (smooth) over repeated runs, and a 3e-2 bound
-    # failed about one run in eight.  6e-2 / 1.5e-1 still rejects any indexing or scaling error (those are O(1)).
-    etol = 6e-2 if fix.endswith("smooth") else 1.5e-1
+    # The forward and every loss value are bit-reproducible run to run (test_forward_is_bit_reproducible), so WHICH pre-activations
+    # sit on the wrong side of zero relative to the oracle is fixed for a given build: the comparison is repeatable up to the
+    # ~1e-7 atomics noise of the default backward (deterministic mode: exactly).  The bound covers the mask flips themselves
+    # (they depend on the kernels' summation order, i.e. they change when a kernel's tiling changes, not between runs).
+    etol = ETOL_SMOOTH if fix.endswith("smooth") else ETOL_DEFAULT
+    seen = []
 
     def l2ok(g, ref, key):
         err = (g.cpu().double() - ref.double()).norm().item()
+        seen.append((err / (ref.double().norm().item() + 1e-5 * gmax / etol), key))
         assert err <= etol * ref.double().norm().item() + 1e-5 * gmax, (key, err, ref.norm().item())
 
     orc = O.OracleTrainer(cfg, nets=nets)
@@ -178,6 +185,8 @@ def test_update_steps_match_reference(T, fix, ltol, gtol):
     orc.gen_update(x_a, x_b, z[3:6], apply=False)
     for (net, k), g in gg.items():
         l2ok(g, orc.nets[net][k].grad, (net, k))
+    seen.sort(reverse=True)
+    print("%s: worst per-tensor relative L2 vs the fp32 oracle:" % fix, [("%.2e" % e, k) for e, k in seen[:3]])
 
     # parameters after Adam: every element moved by at most ~lr on step 1, and the well-conditioned
     # ones agree with the reference's post-step statistics

@@ -228,3 +228,95 @@ def test_full_size_step_properties_16bit(T, dt):
     assert torch.equal(tr._param[0], gen1)
     assert 0 < (tr._param[1] - dis0).abs().max().item() <= 1.01 * cfg["lr"]
     assert np.isfinite(float(tr.loss_dis_total))
+
+
+def test_fp16_at_its_per_gpu_batch_32(T):
+    """BASELINE configs[4] at its real per-GPU workload: fp16 MFMA + dynamic loss scaling, 256x256, B = 256 / 8 GPUs = 32
+    (different split-K plans and a ~4x arena compared with the B=8 test above).
+      * forward parity against the fp32 ORACLE on a 4-sample subset: every normalisation on the path is per sample, so samples
+        0..3 of the B=32 HIP forward must match the oracle run on those four samples alone, within the fp16 bounds stated above;
+      * the step's own fused loss kernels at B=32 against a recomputation from the B=32 public-API forward (L1 identity loss,
+        the LSGAN generator terms): 1e-4;
+      * losses finite, loss scale untouched (no overflow at B=32), the two optimizers stay separate, |first Adam step| <= lr."""
+    dt = "fp16"
+    cfg = O.default_config()
+    cfg["display_size"] = 1
+    nets = O.test_nets(cfg, 0)
+    B, S, NS = 32, 256, 4
+    x_a, x_b, z = _inputs(B, S, 25)
+    tr = _make(T, cfg, nets, dt)
+    xa = x_a.cuda()
+    zz = [t.cuda() for t in z[3:]]
+    # ---- HIP forward at B=32 through the public surface ----
+    c1, _ = tr.gen_AB.encode(xa)
+    c2, s2 = tr.gen_BA.encode(xa)
+    xB4 = tr.gen_AB.decode(c1, zz[0])
+    xB = tr.focus_translation(xB4[:, :3], xa, xB4[:, 3:])
+    xA4 = tr.gen_BA.decode(c2, cfg["alpha"] * zz[1])
+    xA = tr.focus_translation(xA4[:, :3], xa, xA4[:, 3:])
+    rec = tr.gen_BA.decode(c2, s2)
+    c3, _ = tr.gen_BA.encode(xB)
+    xA24 = tr.gen_BA.decode(c3, zz[2])
+    xA2 = tr.focus_translation(xA24[:, :3], xB, xA24[:, 3:])
+    dB = tr.dis_B(xB)
+    dA = tr.dis_A(torch.cat((xA, xA2)))
+    d2 = tr.dis_2(torch.cat((torch.cat((xa, xA), 1), torch.cat((xa, xA2), 1))))
+    # ---- fp32 oracle on samples 0..3 ----
+    with torch.no_grad():
+        _, _, fw = O.gen_losses(nets, x_a[:NS], x_b[:NS], [t[:NS] for t in z[3:]], cfg)
+        dAo = O.dis_forward(nets["dis_A"], fw["x_A_fake"], cfg["dis"])
+    worst = {}
+    for name, got in (("c_1", c1), ("c_2", c2), ("s_2", s2), ("x_B_fake", xB), ("x_A_fake", xA), ("x_A_recon", rec[:, :3]), ("c_3", c3),
+                      ("x_A2_fake", xA2), ("f_B", xB4[:, 3:])):
+        worst[name] = _rel(got[:NS], fw[name])
+    for s_, (g_, w_) in enumerate(zip(dA, dAo)):
+        worst["dis_A_xA_s%d" % s_] = _rel(g_[:NS], w_)
+    print("fp16 B=32 forward max-abs rel errors vs the fp32 oracle on samples 0..3:", {k: "%.2e" % v for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v < FTOL[dt]}
+    assert not bad, bad
+    # ---- the update at B=32 ----
+    gen0 = tr._param[0].clone(); dis0 = tr._param[1].clone()
+    assert tr.grad_scale() == 65536.0
+    tr.gen_update(x_a, x_b, cfg, z=z[3:])
+    torch.cuda.synchronize()
+    want = {"loss_idt_A": (rec[:, :3] - xa).abs().mean().item(),
+            "loss_gen_adv_B": sum(((o - 1) ** 2).mean().item() for o in dB),
+            "loss_gen_adv_A": sum(0.5 * ((o[:B] - 1) ** 2).mean().item() + 0.5 * ((o[B:] - 1) ** 2).mean().item() for o in dA),
+            "loss_gen_adv_2": sum(((o[:B] - 1) ** 2).mean().item() + (o[B:] ** 2).mean().item() for o in d2)}
+    for n, v in want.items():
+        got = float(getattr(tr, n))
+        assert np.isfinite(got) and abs(got - v) <= 1e-4 * max(1e-3, abs(v)), (n, got, v)
+    st = tr.loss_scale_state()
+    assert st["skipped_gen"] == 0 and st["scale"] == 65536.0 and st["clean_updates"] == 1, st
+    assert tr.grad_scale() == 65536.0
+    assert torch.equal(tr._param[1], dis0)
+    d = (tr._param[0] - gen0).abs().max().item()
+    assert 0 < d <= 1.01 * cfg["lr"]
+    gen1 = tr._param[0].clone()
+    tr.dis_update(x_a, x_b, cfg, z=z[:3])
+    torch.cuda.synchronize()
+    assert torch.equal(tr._param[0], gen1)
+    assert 0 < (tr._param[1] - dis0).abs().max().item() <= 1.01 * cfg["lr"]
+    assert np.isfinite(float(tr.loss_dis_total)) and tr.loss_scale_state()["skipped_dis"] == 0
+
+
+def test_fp16_loss_scale_state_survives_a_checkpoint(T, tmp_path):
+    """save() / resume() carry the dynamic loss-scale state (scale, clean counter, skipped-update counts): after a resume Adam's
+    bias-correction step and the live scale continue where they were, and grad_scale() reports the scale the LAST update ran with
+    even after that update halved it."""
+    cfg = O.default_config()
+    cfg["gen"].update(dim=32, mlp_dim=32, n_res=1)
+    cfg["dis"].update(dim=32)
+    cfg["display_size"] = 1
+    cfg["loss_scale_init"] = 2.0 ** 40
+    nets = O.test_nets(cfg, 2)
+    x_a, x_b, z = _inputs(1, 64, 26)
+    tr = _make(T, cfg, nets, "fp16")
+    tr.dis_update(x_a, x_b, cfg, z=z[:3])             # overflows: skipped, scale halves
+    torch.cuda.synchronize()
+    assert tr.loss_scale_state()["scale"] == 2.0 ** 39 and tr.grad_scale() == 2.0 ** 40      # the buffers of that update carry 2^40
+    tr.save(str(tmp_path), 0)
+    tr2 = T.aclgan_Trainer(cfg, compute_dtype="fp16")
+    tr2.resume(str(tmp_path), cfg)
+    a, b = tr.loss_scale_state(), tr2.loss_scale_state()
+    assert a == b and b["skipped_dis"] == 1 and b["scale"] == 2.0 ** 39, (a, b)

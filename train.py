@@ -10,7 +10,14 @@ flip/Resize/crop/ToTensor/Normalize, bit-identical to the reference's torchvisio
 and are zipped exactly like train.py:66; with --synthetic, synthetic U(-1,1) images of the configured crop size
 are used instead.  A configured dataset that does not exist is an error (as in the reference), never a silent
 fallback to noise.  Out of scope: the TensorBoard/HTML writers.  Losses are printed
-every log_iter iterations with ONE device->host copy of the 16-entry loss array instead of 16 (.item() each)."""
+every log_iter iterations with ONE device->host copy of the 16-entry loss array instead of 16 (.item() each).
+
+Data parallel (not in the reference, which is single-GPU: train.py:42): launched as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 train.py --config ...
+every rank binds GPU LOCAL_RANK, joins an RCCL process group, builds a full replica (aclgan_Trainer broadcasts rank 0's weights and
+Adam state and hooks the overlapped gradient all-reduce), reads ITS shard of every global batch (config batch_size is PER GPU; the
+loaders share one seeded permutation per epoch and rank r takes slice r of each global batch) and steps in lockstep; rank 0 alone
+creates directories, copies the config, prints and writes checkpoints."""
 import argparse
 import os
 import shutil
@@ -41,24 +48,45 @@ def main():
     if opts.trainer != "aclgan":
         sys.exit("Only support aclgan")   # train.py:40-41
 
+    # ---- one process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); plain `python train.py` = 1 GPU ----
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ACLGAN_BENCH_SHARE_GPU") == "1":      # test hook (1-GPU box): every rank on GPU 0, gloo instead of RCCL
+        local_rank = 0
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.exit("rank %d: GPU %d not visible (%d devices); there is no CPU fallback" % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        backend = os.environ.get("ACLGAN_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    is_main = rank == 0
+
     import aclgan_amd  # noqa: F401
     from aclgan_amd import _lib as L
     from aclgan_amd.trainer import aclgan_Trainer
 
     config = get_config(opts.config)
     max_iter = opts.max_iter if opts.max_iter is not None else config["max_iter"]
-    trainer = aclgan_Trainer(config)
+    trainer = aclgan_Trainer(config, device="cuda:%d" % local_rank)      # world > 1: broadcasts rank 0's replica, hooks the bucket reducer
     trainer.cuda()
 
     model_name = os.path.splitext(os.path.basename(opts.config))[0]
     output_directory = os.path.join(opts.output_path, "outputs", model_name)
     checkpoint_directory = os.path.join(output_directory, "checkpoints")
-    os.makedirs(checkpoint_directory, exist_ok=True)
-    shutil.copy(opts.config, os.path.join(output_directory, "config.yaml"))   # train.py:61
+    if is_main:
+        os.makedirs(checkpoint_directory, exist_ok=True)
+        shutil.copy(opts.config, os.path.join(output_directory, "config.yaml"))   # train.py:61
+    if world > 1:
+        dist.barrier()      # the checkpoint directory exists before any rank resumes from it
 
     iterations = trainer.resume(checkpoint_directory, hyperparameters=config) if opts.resume else 0
     B, H, W = config["batch_size"], config["crop_image_height"], config["crop_image_width"]
-    gen = torch.Generator().manual_seed(1234)
+    gen = torch.Generator().manual_seed(1234 + rank)      # each rank its own shard of the synthetic global batch
     steps_per_epoch = 1000
 
     def synthetic_epoch():
@@ -67,7 +95,8 @@ def main():
 
     if opts.synthetic:
         epoch = synthetic_epoch
-        print("data: synthetic U(-1,1) batches (--synthetic)")
+        if is_main:
+            print("data: synthetic U(-1,1) batches (--synthetic), %d rank(s) x batch %d" % (world, B))
     else:
         # like the reference (utils.py:43-73 -> data.py ImageFolder raises on a missing / empty folder): a mistyped
         # data_root must not silently train on noise and write checkpoints under the real model name
@@ -77,9 +106,10 @@ def main():
             sys.exit("training images not found (%r): fix data_root / data_folder_train_a in %s, or pass --synthetic "
                      "to train on synthetic U(-1,1) batches" % (folder, opts.config))
         from aclgan_amd.data import get_all_data_loaders
-        train_loader_a, train_loader_b, _, _ = get_all_data_loaders(config)      # train.py:43
+        train_loader_a, train_loader_b, _, _ = get_all_data_loaders(config, device="cuda:%d" % local_rank, rank=rank, world_size=world)   # train.py:43
         epoch = lambda: zip(train_loader_a, train_loader_b)                      # train.py:66
-        print("data: %d / %d training images, device input pipeline" % (len(train_loader_a.source), len(train_loader_b.source)))
+        if is_main:
+            print("data: %d / %d training images, device input pipeline, %d rank(s) x batch %d" % (len(train_loader_a.source), len(train_loader_b.source), world, B))
     while True:
         for it, (images_a, images_b) in enumerate(epoch()):
             t0 = time.time()
@@ -87,18 +117,22 @@ def main():
                 trainer.dis_update(images_a, images_b, config)
             if it % config["G_update"] == 0:          # train.py:73-74
                 trainer.gen_update(images_a, images_b, config)
-            if (iterations + 1) % config["log_iter"] == 0:
+            if is_main and (iterations + 1) % config["log_iter"] == 0:
                 vals = trainer._losses.cpu()          # one D2H copy, implies the sync of train.py:75
                 print("Iteration: %08d/%08d  %.3fs  " % (iterations + 1, max_iter, time.time() - t0) +
                       " ".join("%s=%.4g" % (n[5:], float(vals[i])) for i, n in enumerate(L.LOSS_NAMES)
                                if n in ("loss_gen_total", "loss_dis_total", "loss_idt_A", "loss_gen_adv_A")))
-            if (iterations + 1) % config["snapshot_save_iter"] == 0:
+            if is_main and (iterations + 1) % config["snapshot_save_iter"] == 0:      # replicas are identical: rank 0's copy is THE checkpoint
                 trainer.save(checkpoint_directory, iterations)
             trainer.update_learning_rate()            # train.py:101
             iterations += 1
             if iterations >= max_iter:
-                trainer.save(checkpoint_directory, iterations - 1)
-                print("Finish training")
+                if is_main:
+                    trainer.save(checkpoint_directory, iterations - 1)
+                    print("Finish training")
+                if world > 1:
+                    dist.barrier()
+                    dist.destroy_process_group()
                 return
 
 
