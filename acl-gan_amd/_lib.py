@@ -108,6 +108,14 @@ SIGNATURES = {
     "aclgan_conv2d_fwd16_x16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp, vp]),
     "aclgan_conv2d_dgrad16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp, vp]),
     "aclgan_conv2d_wgrad16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp]),
+    "aclgan_conv16s_ok": (ci, [C.POINTER(ConvDesc), ci]),
+    "aclgan_conv2d_fwd16s": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp]),
+    "aclgan_conv2d_dgrad16s_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
+    "aclgan_conv2d_dgrad16s": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, ci, ci, vp, vp]),
+    "aclgan_conv2d_wgrad16_st": (ci, [C.POINTER(ConvDesc), ci, vp, ci, vp, ci, vp, vp, vp, vp]),
+    "aclgan_cast_storage": (ci, [vp, ci, vp, ci, i64, vp]),
+    "aclgan_norm_fwd_st": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, C.POINTER(ci), vp]),
+    "aclgan_norm_bwd_st": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), vp]),
     "aclgan_conv2d_fwd16_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_dgrad16_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_wgrad16_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),

@@ -198,6 +198,63 @@ int aclgan_conv2d_wgrad16(const aclgan_conv_desc* d, int dtype, const float* x, 
 }
 
 // ---- small dense layers, pooling, blend and loss operators (the step is built from exactly these launchers) ----
+// ---- round 3: the same operators on tensors STORED in the 16-bit compute dtype (storage codes: 0 fp32, ACLGAN_DTYPE_BF16, ACLGAN_DTYPE_FP16) ----
+int aclgan_conv16s_ok(const aclgan_conv_desc* d, int which) {
+    ConvGeom g;
+    return (d && make_geom(d, &g) == 0 && (which == 0 || which == 1) && conv16_eligible(g, which) && conv16s_ok(g, which)) ? 1 : 0;
+}
+int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, const void* w16, const float* bias, void* y, int y_storage, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(y_storage == 0 || y_storage == dtype, "conv2d_fwd16s: y storage must be fp32 or the compute dtype");
+    rc = conv_fwd16s(g, dtype, x16, w16, bias, y, y_storage, (hipStream_t)stream);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_fwd16s: no 16-bit-storage kernel for this shape (no upsample, Cin and Cout multiples of 64, grid >= 96 tiles)");
+    return rc;
+}
+size_t aclgan_conv2d_dgrad16s_scratch_bytes(const aclgan_conv_desc* d) { ConvGeom g; return make_geom(d, &g) ? 0 : conv_dgrad16s_scratch_bytes(g); }
+int aclgan_conv2d_dgrad16s(const aclgan_conv_desc* d, int dtype, const void* dy16, const void* w16t, void* dx, int dx_storage, int accumulate,
+                           void* scratch, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(dx_storage == 0 || dx_storage == dtype, "conv2d_dgrad16s: dx storage must be fp32 or the compute dtype");
+    rc = conv_dgrad16s(g, dtype, dy16, w16t, dx, dx_storage, accumulate, scratch, (hipStream_t)stream);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_dgrad16s: no 16-bit-storage kernel for this shape (no upsample, Cin and Cout multiples of 64)");
+    return rc;
+}
+int aclgan_conv2d_wgrad16_st(const aclgan_conv_desc* d, int dtype, const void* x, int x_storage, const void* dy, int dy_storage, float* dw, float* db,
+                             void* scratch, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE((x_storage == 0 || x_storage == dtype) && (dy_storage == 0 || dy_storage == dtype), "conv2d_wgrad16_st: storage must be fp32 or the compute dtype");
+    rc = conv_wgrad16(g, dtype, (const float*)x, (const float*)dy, dw, db, scratch, (hipStream_t)stream, x_storage, dy_storage);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_wgrad16: no 16-bit kernel for this shape (Cin, Cout must be multiples of 64)");
+    return rc;
+}
+int aclgan_cast_storage(const void* src, int src_storage, void* dst, int dst_storage, int64_t n, void* stream) {
+    ACL_REQUIRE(src && dst && src_storage >= 0 && src_storage <= 2 && dst_storage >= 0 && dst_storage <= 2, "cast_storage: bad argument");
+    return cast_storage(src, src_storage, dst, dst_storage, n, (hipStream_t)stream);
+}
+// storage[3] = {x, y, residual}
+int aclgan_norm_fwd_st(int kind, int act, int B, int HW, int C, const void* x, const float* w, const float* b, int w_stride, const void* residual,
+                       void* y, float* mean, float* rstd, void* scratch, const int* storage, void* stream) {
+    ACL_REQUIRE(storage, "norm_fwd_st: storage codes missing");
+    NormST s;
+    s.x = storage[0]; s.y = storage[1]; s.res = storage[2];
+    return norm_fwd(kind, act, B, HW, C, x, w, b, w_stride, residual, y, mean, rstd, scratch, (hipStream_t)stream, nullptr, 0, &s);
+}
+// storage[6] = {x, y, dy, dx, dres, unused}
+int aclgan_norm_bwd_st(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy, const float* w, int w_stride,
+                       const float* mean, const float* rstd, void* dx, float* dw, float* db, void* dres, int dres_accumulate, void* scratch,
+                       const int* storage, void* stream) {
+    ACL_REQUIRE(storage, "norm_bwd_st: storage codes missing");
+    NormST s;
+    s.x = storage[0]; s.y = storage[1]; s.dy = storage[2]; s.dx = storage[3]; s.dres = storage[4];
+    return norm_bwd(kind, act, B, HW, C, x, y, dy, w, w_stride, mean, rstd, dx, dw, db, dres, dres_accumulate, scratch, (hipStream_t)stream, &s);
+}
+
 int aclgan_linear_fwd(int B, int I, int O, const float* x, const float* w, const float* bias, int act, float* y, void* stream) {
     ACL_REQUIRE(B > 0 && I > 0 && O > 0 && x && w && y, "linear_fwd: bad arguments");
     return linear_fwd(B, I, O, x, w, bias, act, y, (hipStream_t)stream);

@@ -112,11 +112,21 @@ size_t conv_dgrad16_scratch_bytes(const ConvGeom& g);
 size_t conv_wgrad16_scratch_bytes(const ConvGeom& g);
 // w: fp32 OHWI master weights (only read by the sub-pixel path, to merge the phase filters before rounding); w16: OHWI 16-bit pack
 // x16 (optional): the producer's 16-bit copy of x (same layout) -- read instead of x, same result
+// y_storage != 0: y is stored in the 16-bit dtype (and points at 16-bit data)
 int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st,
-               const void* x16 = nullptr);
+               const void* x16 = nullptr, int y_storage = 0);
 // w16t: 16-bit pack transposed to [tap][cin][cout]; dx is complete on return (interior + mirrored halo)
 int conv_dgrad16(const ConvGeom& g, int dtype, const float* dy, const float* w, const void* w16t, float* dx, int accumulate, void* scratch, hipStream_t st);
-int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
+// x_storage / dy_storage != 0: that operand is stored in the 16-bit dtype (the pointer then addresses 16-bit data)
+int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, int x_storage = 0,
+                 int dy_storage = 0);
+
+// 16-bit ACTIVATION STORAGE kernels (conv_glds16.hip): operands already live in HBM in the 16-bit dtype, tiles go global -> LDS directly.
+// which: 0 forward, 1 dgrad.  No upsample, Cin % 64 == 0, Cout % 64 == 0.
+bool conv16s_ok(const ConvGeom& g, int which);
+int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st);
+size_t conv_dgrad16s_scratch_bytes(const ConvGeom& g);
+int conv_dgrad16s(const ConvGeom& g, int dtype, const void* dy16, const void* w16t, void* dx, int dxst, int accumulate, void* scratch, hipStream_t st);
 int cast_flat16(const float* src, void* dst, int64_t n, int dtype, hipStream_t st);
 int transpose_flat16(const float* base, void* base_t, const int64_t* offs, const int* co, const int* taps, const int* ci, int n, int dtype, hipStream_t st);
 
@@ -127,14 +137,20 @@ size_t conv_wgrad_small_scratch_bytes(const ConvGeom& g);
 int conv_dgrad_small(const ConvGeom& g, const float* dy, const float* w, float* dxp, hipStream_t st);
 
 size_t norm_scratch_bytes(int B, int HW, int C);
-int norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const float* w, const float* b, int w_stride,
-             const float* residual, float* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats = nullptr,
-             int stats_chunk = 0);
-int norm_bwd(int kind, int act, int B, int HW, int C, const float* x, const float* y, const float* dy,
-             const float* w, int w_stride, const float* mean, const float* rstd, float* dx, float* dw, float* db,
-             float* dres, int dres_accumulate, void* scratch, hipStream_t st);
+// storage codes (st16.h: 0 fp32, ACLGAN_DTYPE_BF16, ACLGAN_DTYPE_FP16) of the tensors a normalisation call touches; statistics,
+// coefficients and parameter gradients are always fp32
+struct NormST { int x = 0, y = 0, res = 0, dy = 0, dx = 0, dres = 0; };
+int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float* w, const float* b, int w_stride,
+             const void* residual, void* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats = nullptr,
+             int stats_chunk = 0, const NormST* sto = nullptr);
+int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy,
+             const float* w, int w_stride, const float* mean, const float* rstd, void* dx, float* dw, float* db,
+             void* dres, int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto = nullptr);
 
-int act_bwd_inplace(int act, const float* y, float* dy, int64_t n, hipStream_t st);
+// dy *= act'(y) (y, dy may be stored in different dtypes; n % 4 == 0 unless both are fp32)
+int act_bwd_inplace(int act, const void* y, void* dy, int64_t n, hipStream_t st, int yst = 0, int gst = 0);
+// dst (storage dst_st) = src (storage src_st), elementwise conversion; n % 4 == 0
+int cast_storage(const void* src, int src_st, void* dst, int dst_st, int64_t n, hipStream_t st);
 int avgpool3s2_fwd(int B, int H, int W, int C, const float* x, float* y, hipStream_t st);
 int avgpool3s2_bwd(int B, int H, int W, int C, const float* dy, float* dx, int accumulate, hipStream_t st);
 int adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const aclgan_adam* o, int step, hipStream_t st);
@@ -147,9 +163,9 @@ int linear_fwd(int B, int I, int O, const float* x, const float* w, const float*
 // dy is modified in place by the activation backward; dx overwritten (may be null); dw,db accumulate
 int linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, const float* w, int act,
                float* dx, float* dw, float* db, hipStream_t st);
-// global average pool NHWC [B][HW][C] -> [B][C]
-int gap_fwd(int B, int HW, int C, const float* x, float* y, hipStream_t st);
-int gap_bwd(int B, int HW, int C, const float* dy, float* dx, int accumulate, hipStream_t st);
+// global average pool NHWC [B][HW][C] (storage xst) -> [B][C] fp32; backward writes dx in storage xst
+int gap_fwd(int B, int HW, int C, const void* x, float* y, hipStream_t st, int xst = 0);
+int gap_bwd(int B, int HW, int C, const float* dy, void* dx, int accumulate, hipStream_t st, int xst = 0);
 
 // trainer-level fused kernels
 // focus_translation (trainer.py:85-88): dec4 [B][HW][4] (ch0-2 fg, ch3 focus), bg [B][HW][3] -> out [B][HW][3];

@@ -21,6 +21,7 @@
 //     8 pixels x 4 channels (8 coalesced dwordx4 loads), transposes in registers and writes 4 b128 rows [channel][8 px];
 //     rows are stored interleaved (row = (ch%4)*(rows/4) + ch/4) so that the 32 lanes of a write hit consecutive rows.
 #include "conv_fast_common.h"
+#include "st16.h"
 
 namespace aclgan {
 namespace {
@@ -215,10 +216,28 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_fwd16_kernel(FwdFP p) {
                 const int o = ro[rl];
                 if (o >= 0) {
                     if (split) p.part[((size_t)blockIdx.z * p.rows + m0 + rl) * p.Co + n] = acc[i][j][r];   // ordered partials (always)
-                    else p.y[(size_t)o * p.Co + n] = act_apply(acc[i][j][r] + bv, p.act);
+                    else st_st1(p.y, (int64_t)o * p.Co + n, act_apply(acc[i][j][r] + bv, p.act), p.yst);
                 }
             }
         }
+    }
+}
+
+// ordered reduction of the split-K partials into a y of any storage dtype (Co % 4 == 0)
+__global__ void fwd_split_finish_st_kernel(FwdFP p, int splits) {
+    const int C4 = p.Co >> 2;
+    const int64_t n = (int64_t)p.rows * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / C4), c4 = (int)(i - (int64_t)m * C4);
+        int b, oy, ox;
+        if (!fwd_row(p, m, b, oy, ox)) continue;
+        f32x4 s = *reinterpret_cast<const f32x4*>(p.part + (size_t)m * p.Co + c4 * 4);
+        for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(p.part + ((size_t)z * p.rows + m) * p.Co + c4 * 4);
+        if (p.bias) s += *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
+        st_f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_apply(s[e], p.act);
+        st_st4(p.y, ((int64_t)(b * p.Ho + oy) * p.Wo + ox) * C4 + c4, o, p.yst);
     }
 }
 
@@ -242,7 +261,8 @@ int launch_fwd16(const ConvGeom& g, FwdFP p, hipStream_t st) {
     else hipLaunchKernelGGL((conv_fwd16_kernel<T, KS, WM, WN, TM, TN, false>), dim3(p.nwg, 1, splits), dim3(WM * WN * 64), 0, st, p);
     ACL_CHECK_LAUNCH("conv_fwd16_kernel");
     if (splits > 1) {
-        hipLaunchKernelGGL(fwd_split_finish_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)rows * std::max(1, g.Co / 4), 256), 4096)), dim3(256), 0, st, p, splits);
+        if (p.yst == ST_F32) hipLaunchKernelGGL(fwd_split_finish_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)rows * std::max(1, g.Co / 4), 256), 4096)), dim3(256), 0, st, p, splits);
+        else hipLaunchKernelGGL(fwd_split_finish_st_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)rows * (g.Co / 4), 256), 4096)), dim3(256), 0, st, p, splits);
         ACL_CHECK_LAUNCH("fwd_split_finish_kernel");
     }
     return ACLGAN_OK;
@@ -516,6 +536,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, WgPa
     const int ncg = (isA ? BM : BN) >> 2;           // channel groups of the tile
     const int cg = u % ncg, pg = u / ncg;           // pg in 0..3: pixels 8pg .. 8pg+7 of the k-tile
     const float* src = isA ? p.dy : p.x;
+    const int myst = isA ? p.dyst : p.xst;          // storage of this thread's operand (st16.h); 16-bit: src points at 16-bit data
     const int cstride = isA ? p.Co : p.Ci;
     const int chan = isA ? m0 + 4 * cg : (n0 - st_tap * p.Ci) + 4 * cg;
     u32x4* mytile = isA ? As : Bs;
@@ -547,28 +568,63 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, WgPa
         auto fetch = [&](int kt) __attribute__((always_inline)) {
             const int pb = kt * BK16 + 8 * pg;    // sub-chunk relative
             if (isA || isB) {
+                if (myst == ST_F32) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int2 pi = pinfo[pb + j];
-                    rr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
-                    zm[j] = cb + pb + j < ce ? 1.f : 0.f;     // pixels past the sub-chunk contribute nothing (masking both operands is harmless)
+                    for (int j = 0; j < 8; ++j) {
+                        const int2 pi = pinfo[pb + j];
+                        rr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
+                        zm[j] = cb + pb + j < ce ? 1.f : 0.f;     // pixels past the sub-chunk contribute nothing (masking both operands is harmless)
+                    }
+                } else {      // 16-bit storage: 4 channels = 8 bytes per pixel, kept in the first two lanes of rr[j]
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int2 pi = pinfo[pb + j];
+                        const st_u32x2 h = *reinterpret_cast<const st_u32x2*>(reinterpret_cast<const u16*>(src) + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
+                        rr[j][0] = __builtin_bit_cast(float, h[0]); rr[j][1] = __builtin_bit_cast(float, h[1]);
+                        zm[j] = cb + pb + j < ce ? 1.f : 0.f;
+                    }
                 }
             }
         };
         auto stage = [&](int buf, bool real) __attribute__((always_inline)) {
             if (isA || isB) {
                 u32x4* t = mytile + buf * tstride;
-                f32x4 v[8];
+                if (myst == ST_F32) {
+                    f32x4 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = rr[j] * zm[j];
-                if (isA && real) {
+                    for (int j = 0; j < 8; ++j) v[j] = rr[j] * zm[j];
+                    if (do_bias && isA && real) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum += v[j];
-                }
+                        for (int j = 0; j < 8; ++j) bsum += v[j];
+                    }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x8 k8 = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
-                    t[(c * ncg + cg) * LDQ + pg] = T::pack(k8);     // row interleave: channel 4cg+c -> row c*ncg + cg
+                    for (int c = 0; c < 4; ++c) {
+                        f32x8 k8 = {v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], v[6][c], v[7][c]};
+                        t[(c * ncg + cg) * LDQ + pg] = T::pack(k8);     // row interleave: channel 4cg+c -> row c*ncg + cg
+                    }
+                } else {
+                    unsigned int h[8][2];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        h[j][0] = zm[j] != 0.f ? __builtin_bit_cast(unsigned int, rr[j][0]) : 0u;
+                        h[j][1] = zm[j] != 0.f ? __builtin_bit_cast(unsigned int, rr[j][1]) : 0u;
+                    }
+                    if (do_bias && isA && real) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const st_f32x2 a = st_unpack2(h[j][0], myst), b2 = st_unpack2(h[j][1], myst);
+                            bsum[0] += a[0]; bsum[1] += a[1]; bsum[2] += b2[0]; bsum[3] += b2[1];
+                        }
+                    }
+                    // 8 pixels x 4 channels of 16-bit values -> per channel 8 consecutive pixels (v_perm_b32: two halves per instruction)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned int sel = (c & 1) ? 0x07060302u : 0x05040100u;
+                        u32x4 k8;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) k8[q] = __builtin_amdgcn_perm(h[2 * q + 1][c >> 1], h[2 * q][c >> 1], sel);
+                        t[(c * ncg + cg) * LDQ + pg] = k8;
+                    }
                 }
             }
         };
@@ -732,8 +788,9 @@ bool wgrad16_ok(const ConvGeom& g) { return fast_enabled() && g.Co % 64 == 0 && 
 
 size_t up5_w16_bytes(const ConvGeom& g) { return ((size_t)4 * g.Co * 9 * g.Ci * sizeof(u16) + 255) & ~(size_t)255; }
 
-FwdFP fwd_params(const ConvGeom& g, const float* x, const u16* w16, const float* bias, float* y, const u16* x16 = nullptr) {
+FwdFP fwd_params(const ConvGeom& g, const float* x, const u16* w16, const float* bias, float* y, const u16* x16 = nullptr, int yst = 0) {
     FwdFP p;
+    p.yst = yst;
     p.part = nullptr; p.rows = 0; p.w = nullptr; p.w16 = w16; p.x16 = x16;
     p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0;
     p.x = x; p.bias = bias; p.y = y;
@@ -786,7 +843,7 @@ int launch_wgrad16_any(const ConvGeom& g, const WgFP& p, void* part, hipStream_t
     return launch_wgrad16<T, 2, 2, 1, 1>(g, p, part, st);                                            // 64 x 64: half the threads stage
 }
 template <class T>
-int fwd16_t(const ConvGeom& g, const float* x, const u16* x16, const float* w, const u16* w16, const float* bias, float* y, void* scratch, hipStream_t st) {
+int fwd16_t(const ConvGeom& g, const float* x, const u16* x16, const float* w, const u16* w16, const float* bias, float* y, void* scratch, hipStream_t st, int yst) {
     if (up5_eligible(g)) {
         if (!scratch || !w) { set_error("conv_fwd16: the upsample+5x5 layer needs its scratch buffer and the fp32 weights"); return ACLGAN_EINVAL; }
         u16* wp = (u16*)scratch;
@@ -794,7 +851,7 @@ int fwd16_t(const ConvGeom& g, const float* x, const u16* x16, const float* w, c
         hipLaunchKernelGGL(up5_merge16_kernel<T>, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, (u16*)nullptr, g.Co, g.Ci);
         ACL_CHECK_LAUNCH("up5_merge16_kernel");
         // (1) the four phases: VALID 3x3 conv on the low-res input with the merged weights
-        FwdFP p = fwd_params(g, x, wp, bias, y, x16);
+        FwdFP p = fwd_params(g, x, wp, bias, y, x16, yst);
         p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.k = 3; p.s = 1; p.p = 0; p.up = 0; p.Hu = g.Hi; p.Wu = g.Wi;
         p.M = g.B * p.Ho * p.Wo; p.K = 9 * g.Ci; p.phases = 1; p.Hf = g.Ho; p.Wf = g.Wo;
         ConvGeom gp = g;
@@ -802,12 +859,12 @@ int fwd16_t(const ConvGeom& g, const float* x, const u16* x16, const float* w, c
         int rc = launch_fwd16_any<T>(gp, p, st);
         if (rc) return rc;
         // (2) the output ring of width 2: exact 5x5 gather (reflection at the borders of the upsampled image)
-        p = fwd_params(g, x, w16, bias, y, x16);
+        p = fwd_params(g, x, w16, bias, y, x16, yst);
         p.ring = 2;
         p.part = (float*)((char*)scratch + up5_w16_bytes(g));
         return launch_fwd16_any<T>(g, p, st);
     }
-    FwdFP p = fwd_params(g, x, w16, bias, y, x16);
+    FwdFP p = fwd_params(g, x, w16, bias, y, x16, yst);
     p.part = (float*)scratch;
     return launch_fwd16_any<T>(g, p, st);
 }
@@ -872,8 +929,9 @@ int dgrad16_t(const ConvGeom& g, const float* dy, const float* w, const u16* w16
     return rc;
 }
 
-WgFP wg_params(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db) {
+WgFP wg_params(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, int xst = 0, int dyst = 0) {
     WgFP p;
+    p.xst = xst; p.dyst = dyst;
     p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_dy = 0;
     p.x = x; p.dy = dy; p.dw = dw; p.db = db;
     p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
@@ -885,14 +943,14 @@ WgFP wg_params(const ConvGeom& g, const float* x, const float* dy, float* dw, fl
 size_t wgrad16_scratch(const ConvGeom& g) { return wgrad_part_scratch(g, BK16, WG16_TARGET); }
 
 template <class T>
-int wgrad16_t(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
+int wgrad16_t(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, int xst, int dyst) {
     if (wgrad16_scratch(g) && !scratch) { set_error("conv_wgrad16: this layer needs its scratch buffer"); return ACLGAN_EINVAL; }
     if (up5_eligible(g)) {
         float* dwp = (float*)scratch;
         void* part = (char*)scratch + up5_dwp_bytes(g);
         hipError_t e = hipMemsetAsync(dwp, 0, (size_t)4 * g.Co * 9 * g.Ci * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "memset dwp");
-        WgFP p = wg_params(g, x, dy, dwp, db);
+        WgFP p = wg_params(g, x, dy, dwp, db, xst, dyst);
         p.Ho = g.Hi - 2; p.Wo = g.Wi - 2; p.k = 3; p.s = 1; p.p = 0; p.up = 0; p.Hu = g.Hi; p.Wu = g.Wi;
         p.P = g.B * p.Ho * p.Wo; p.Kn = 9 * g.Ci; p.phases = 1; p.Hf = g.Ho; p.Wf = g.Wo;
         int rc = launch_wgrad16_any<T>(g, p, part, st);
@@ -900,12 +958,12 @@ int wgrad16_t(const ConvGeom& g, const float* x, const float* dy, float* dw, flo
         const int64_t ns = (int64_t)g.Co * 25 * (g.Ci / 4);
         hipLaunchKernelGGL(up5_scatter_kernel, dim3((int)std::min<int64_t>(cdiv64(ns, 256), 2048)), dim3(256), 0, st, dwp, dw, g.Co, g.Ci);
         ACL_CHECK_LAUNCH("up5_scatter_kernel");
-        p = wg_params(g, x, dy, dw, db);
+        p = wg_params(g, x, dy, dw, db, xst, dyst);
         p.ring = 2;
         p.P = up5_ring_pixels(g);
         return launch_wgrad16_any<T>(g, p, part, st);
     }
-    return launch_wgrad16_any<T>(g, wg_params(g, x, dy, dw, db), scratch, st);
+    return launch_wgrad16_any<T>(g, wg_params(g, x, dy, dw, db, xst, dyst), scratch, st);
 }
 
 }  // namespace
@@ -930,10 +988,11 @@ size_t conv_dgrad16_scratch_bytes(const ConvGeom& g) {
 size_t conv_wgrad16_scratch_bytes(const ConvGeom& g) { return wgrad16_ok(g) ? wgrad16_scratch(g) : 0; }
 
 int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st,
-               const void* x16) {
+               const void* x16, int y_storage) {
     if (!fwd16_ok(g)) return ACLGAN_EUNSUPPORTED;
-    if (dtype == ACLGAN_DTYPE_BF16) return fwd16_t<PBF16>(g, x, (const u16*)x16, w, (const u16*)w16, bias, y, scratch, st);
-    if (dtype == ACLGAN_DTYPE_FP16) return fwd16_t<PFP16>(g, x, (const u16*)x16, w, (const u16*)w16, bias, y, scratch, st);
+    const int yst = y_storage ? dtype : 0;
+    if (dtype == ACLGAN_DTYPE_BF16) return fwd16_t<PBF16>(g, x, (const u16*)x16, w, (const u16*)w16, bias, y, scratch, st, yst);
+    if (dtype == ACLGAN_DTYPE_FP16) return fwd16_t<PFP16>(g, x, (const u16*)x16, w, (const u16*)w16, bias, y, scratch, st, yst);
     set_error("conv_fwd16: dtype %d", dtype);
     return ACLGAN_EINVAL;
 }
@@ -944,10 +1003,12 @@ int conv_dgrad16(const ConvGeom& g, int dtype, const float* dy, const float* w, 
     set_error("conv_dgrad16: dtype %d", dtype);
     return ACLGAN_EINVAL;
 }
-int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st) {
+int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, int x_storage,
+                 int dy_storage) {
     if (!wgrad16_ok(g) || !dw) return ACLGAN_EUNSUPPORTED;
-    if (dtype == ACLGAN_DTYPE_BF16) return wgrad16_t<PBF16>(g, x, dy, dw, db, scratch, st);
-    if (dtype == ACLGAN_DTYPE_FP16) return wgrad16_t<PFP16>(g, x, dy, dw, db, scratch, st);
+    const int xst = x_storage ? dtype : 0, dyst = dy_storage ? dtype : 0;
+    if (dtype == ACLGAN_DTYPE_BF16) return wgrad16_t<PBF16>(g, x, dy, dw, db, scratch, st, xst, dyst);
+    if (dtype == ACLGAN_DTYPE_FP16) return wgrad16_t<PFP16>(g, x, dy, dw, db, scratch, st, xst, dyst);
     set_error("conv_wgrad16: dtype %d", dtype);
     return ACLGAN_EINVAL;
 }

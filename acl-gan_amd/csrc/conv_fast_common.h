@@ -64,6 +64,7 @@ struct FwdFP {
     // fs_* floats after those of slice 0.  0 = off.
     int fsl; long long fs_x, fs_w, fs_y;
     int fsx_mod;                 // > 0: the x operand of slice f is plane f % fsx_mod
+    int yst = 0;                 // 16-bit kernels: storage of y (st16.h: 0 fp32, else the 16-bit compute dtype); y then points at 16-bit data
 };
 
 __device__ __forceinline__ bool fwd_row(const FwdFP& p, int m, int& b, int& oy, int& ox) {
@@ -257,6 +258,7 @@ struct WgFP {
     // dw + z*dw_zs / db + z*db_zs (one writer per element), reduce_slices_ordered adds the copies in order.  0 = shared dw / db.
     long long dw_zs = 0, db_zs = 0;
     int dw_overwrite = 0;        // ordered-slice launches: wgrad_finish_kernel stores the sum (dw = ...) instead of accumulating (dw += ...)
+    int xst = 0, dyst = 0;       // 16-bit kernels: storage of x / dy (st16.h); non-zero: the pointer addresses 16-bit data
 };
 
 __device__ __forceinline__ void wg_coord(const WgFP& p, int pix, int& b, int& oy, int& ox) {

@@ -1,0 +1,427 @@
+// conv_glds16.hip -- round 3: the heavy convolutions of the 16-bit compute dtypes on 16-BIT ACTIVATIONS / GRADIENTS IN HBM, operand
+// tiles loaded global -> LDS directly (buffer_load_dwordx4 ... lds), no VGPR staging, no conversion, no ds_write.
+//
+//   forward   networks.py:366 (ReflectionPad2d + Conv2d + bias [+ activation])           conv_fwd16s
+//   dgrad     autograd of the same line w.r.t. its input (trainer.py:169,292)             conv_dgrad16s  (padded grid + ordered fold)
+//
+// Why a second kernel family next to conv_fast16.hip: with fp32 activations in HBM the 16-bit MFMA kernels sat at 0.21 of the
+// 2.5 PFLOP/s roof (round 2, profiles/r02_pmc_conv16.txt): 6.5 VALU instructions per MFMA -- 64-bit address arithmetic of six global
+// loads per k-tile, eight v_cvt_pk, the register -> LDS staging writes -- and twice the operand bytes.  Here the producers (norm_apply,
+// the conv epilogues, norm_bwd_apply, the fold) store bf16 / fp16, so an operand tile row is 128 contiguous BYTES of HBM that one
+// quarter-wave copies straight into LDS; the per-lane work per k-tile is eight LDS-DMA issues with an SGPR k offset.
+//
+// Tile: 128 (pixels) x 128 | 64 (channels) x 64 (k) per workgroup of 4 waves (2 x 2, 64 x 64 | 64 x 32 per wave, 32x32x16 MFMA),
+// two LDS buffers of 32 KB | 24 KB, two workgroups per CU.  LDS image = [row][64 halfs] with no padding (LDS-DMA writes are
+// lane-linear: wave-uniform base + 16 B x lane); bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of
+// the 16-byte chunk index with (row >> 1) & 7, applied to the per-lane SOURCE address of the DMA and to the fragment read address
+// (cdna_hip_programming.md rule 21: both sides or neither).  One barrier per k-tile: the DMA of tile t+1 is issued right after the
+// barrier that publishes tile t and lands while tile t's 16 MFMAs per wave run.
+//
+// Out-of-range operand rows (dgrad: a filter tap that reaches outside the output map) point their DMA lanes past the end of the
+// tensor's buffer descriptor: a raw buffer load returns zero for such lanes.
+//
+// The reflection halo of dgrad: ONE launch over the padded grid (every padded position has exactly one writer), then an ordered
+// gather (conv_fold_st) folds the reflection onto dx -- no atomics, reproducible bit for bit, and the only plan that can write a
+// 16-bit dx.
+#include "conv_fast_common.h"
+#include "st16.h"
+
+namespace aclgan {
+namespace {
+
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct QBF16 {
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+struct QFP16 {
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+constexpr int ROWB = 128;          // bytes per LDS row = 64 halfs = one k-tile
+constexpr int OOB = 0x7ffffff0;    // voffset of a DMA lane that must read zero (beyond any num_records)
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7fffffe0ll ? 0x7fffffe0ll : bytes), 0x00020000);
+}
+
+// one k-tile of MFMAs from LDS buffers a (this wave's 64 rows start at row ra) and b (rows rb): TM x TN tiles, 4 k-steps of 16
+template <class T, int TM, int TN>
+__device__ __forceinline__ void mma_tile(const unsigned char* a, const unsigned char* b, int lane, f32x16 (&acc)[TM][TN]) {
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int c0 = kh ^ ((l31 >> 1) & 7);            // chunk (2 ks + kh) ^ sw  =  (2 ks) ^ c0
+    u32x4 fa[TM][4], fb[TN][4];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(a + (t * 32 + l31) * ROWB + ((c0 ^ (2 * ks)) << 4));
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(b + (t * 32 + l31) * ROWB + ((c0 ^ (2 * ks)) << 4));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
+}
+
+// store a wave's accumulators: element (row-index table ro[], column n) of a [rows][ld] matrix of storage `yst`.
+// fp32: one dword per value.  16-bit: lanes l and l^1 hold columns n and n^1 of the same 16 rows -- they swap (DPP) and each stores
+// eight packed dwords (even lane: rows with even r, odd lane: odd r) instead of sixteen 2-byte stores.
+template <int TM, int TN, class F>
+__device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], const int* ro, int rbase, int nbase, int nmax, int ld, void* __restrict__ y,
+                                          int yst, int lane, F&& fin) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (yst == ST_F32) {
+                if (n < nmax) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = ro[rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                        if (o >= 0) reinterpret_cast<float*>(y)[(size_t)o * ld + n] = fin(acc[i][j][r], n);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    // values of this lane for rows r, r+1; the partner (l ^ 1) holds the neighbouring column of the same rows
+                    const float v0 = n < nmax ? fin(acc[i][j][r], n) : 0.f, v1 = n < nmax ? fin(acc[i][j][r + 1], n) : 0.f;
+                    const float p0 = __shfl_xor(v0, 1), p1 = __shfl_xor(v1, 1);
+                    const bool odd = l31 & 1;
+                    const int rr = odd ? r + 1 : r;
+                    const int o = ro[rbase + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh];
+                    const unsigned int pk = odd ? st_pack2(p1, v1, yst) : st_pack2(v0, p0, yst);
+                    if (o >= 0 && (n & ~1) < nmax) *reinterpret_cast<unsigned int*>(reinterpret_cast<u16*>(y) + (size_t)o * ld + (n & ~1)) = pk;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+struct FwdSP {
+    const u16* x16; const u16* w16; const float* bias; void* y;
+    int B, Hi, Wi, Ci, Ho, Wo, Co, k, s, p, M, K, act, tiles_n, nwg, yst;
+    float2* stats;     // optional: per (128-row tile, channel) (mean, M2) of the stored outputs -- the normalisation layer's chunk partials
+};
+
+template <class T, int BN>
+__global__ void __launch_bounds__(256, 2) conv_fwd16s_kernel(FwdSP p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (device pass only: the host pass cannot instantiate a template body that declares __amdgpu_buffer_rsrc_t locals -- its launch stub would stay undefined)
+
+    constexpr int BM = 128, TM = 2, TN = BN / 64, B_IT = BN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES) + BM * 4];
+    int* ro = reinterpret_cast<int*>(smem + 2 * (A_BYTES + B_BYTES));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_map(blockIdx.x, p.nwg);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int hw = p.Ho * p.Wo;
+
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        ro[r] = m < p.M ? m : -1;                 // output pixel index == GEMM row (NHWC, no phases / rings here)
+    }
+    // DMA rows of this lane: A rows 32 wave + 8 n + (lane >> 3), n = 0..3; the lane copies chunk (lane & 7) ^ swz(row) of its rows
+    const int lr = lane >> 3, lj = lane & 7;
+    int ay[4], ax[4], ab[4], acs[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int row = 32 * wave + 8 * n + lr;
+        const int m = min(m0 + row, p.M - 1);     // past the end: any valid row (never stored)
+        const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        ay[n] = oy * p.s - p.p; ax[n] = ox * p.s - p.p; ab[n] = b * p.Hi * p.Wi;
+        acs[n] = (lj ^ ((row >> 1) & 7)) * 8;
+    }
+    int bvo[B_IT];
+#pragma unroll
+    for (int n = 0; n < B_IT; ++n) {
+        const int row = (BN / 4) * wave + 8 * n + lr;
+        bvo[n] = (min(n0 + row, p.Co - 1) * p.K + (lj ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x16, (long long)p.B * p.Hi * p.Wi * p.Ci * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16, (long long)p.Co * p.K * 2);
+    const int cpt = p.Ci >> 6;                     // k-tiles per filter tap
+    const int nk = p.K >> 6;
+    int avo[4];
+    int f_tap = -1;
+
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        const int tap = kt / cpt, cc = kt - tap * cpt;
+        if (tap != f_tap) {                        // block-uniform: new filter tap -> redo the gather offsets
+            f_tap = tap;
+            const int ky = tap / p.k, kx = tap - ky * p.k;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int iy = refl(ay[n] + ky, p.Hi), ix = refl(ax[n] + kx, p.Wi);
+                avo[n] = ((ab[n] + iy * p.Wi + ix) * p.Ci + acs[n]) * 2;
+            }
+        }
+        unsigned char* da = smem + buf * A_BYTES + (32 * wave) * ROWB;
+        unsigned char* db = smem + 2 * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
+#pragma unroll
+        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], kt * 128, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();                           // (vmcnt(0) +) barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + 2 * A_BYTES + cur * B_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+    }
+
+    const float* bias = p.bias;
+    const int act = p.act;
+    store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Co, p.Co, p.y, p.yst, lane,
+                      [&](float v, int n) { return act_apply(v + (bias ? bias[n] : 0.f), act); });
+#endif
+}
+
+template <class T>
+int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
+    const int BN = g.Co % 128 == 0 ? 128 : 64;
+    p.tiles_n = g.Co / BN;
+    p.nwg = cdiv(g.M, 128) * p.tiles_n;
+    if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128>), dim3(p.nwg), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 64>), dim3(p.nwg), dim3(256), 0, st, p);
+    ACL_CHECK_LAUNCH("conv_fwd16s_kernel");
+    return ACLGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// dgrad over the padded grid (GEMM rows = padded positions of one stride-parity class, k = (tap of the class, cout), n = cin)
+// ------------------------------------------------------------------------------------------
+struct DgSP {
+    const u16* dy16; const u16* w16t; void* dxp;
+    int B, Ho, Wo, Co, Ci, k, s, Hp, Wp, Hc, Wc, Mc, tiles_n, nwg, pst;
+};
+
+template <class T, int BN>
+__global__ void __launch_bounds__(256, 2) conv_dgrad16s_kernel(DgSP p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (device pass only: the host pass cannot instantiate a template body that declares __amdgpu_buffer_rsrc_t locals -- its launch stub would stay undefined)
+
+    constexpr int BM = 128, TM = 2, TN = BN / 64, B_IT = BN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES) + BM * 4];
+    int* ro = reinterpret_cast<int*>(smem + 2 * (A_BYTES + B_BYTES));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_map(blockIdx.x, p.nwg);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int cls = blockIdx.z, cy = cls / p.s, cx = cls - cy * p.s;
+    const int Tx = (p.k - cx + p.s - 1) / p.s, Ty = (p.k - cy + p.s - 1) / p.s;
+    const int hwc = p.Hc * p.Wc;
+
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int oo = -1;
+        if (m < p.Mc) {
+            const int b = m / hwc, rem = m - b * hwc, y2 = rem / p.Wc, x2 = rem - y2 * p.Wc;
+            const int py = y2 * p.s + cy, px = x2 * p.s + cx;
+            if (py < p.Hp && px < p.Wp) oo = (b * p.Hp + py) * p.Wp + px;
+        }
+        ro[r] = oo;
+    }
+    const int lr = lane >> 3, lj = lane & 7;
+    int ay[4], ax[4], ab[4], acs[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int row = 32 * wave + 8 * n + lr;
+        const int m = m0 + row;
+        if (m < p.Mc) {
+            const int b = m / hwc, rem = m - b * hwc, y2 = rem / p.Wc;
+            ay[n] = y2; ax[n] = rem - y2 * p.Wc; ab[n] = b;
+        } else { ay[n] = -100000; ax[n] = -100000; ab[n] = 0; }      // reads zero for every tap
+        acs[n] = (lj ^ ((row >> 1) & 7)) * 8;
+    }
+    // B rows = input channels n, k = 64 consecutive cout of one tap: w16t[tap][n][cout]
+    int bvo[B_IT];
+#pragma unroll
+    for (int n = 0; n < B_IT; ++n) {
+        const int row = (BN / 4) * wave + 8 * n + lr;
+        bvo[n] = (min(n0 + row, p.Ci - 1) * p.Co + (lj ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy16, (long long)p.B * p.Ho * p.Wo * p.Co * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16t, (long long)p.k * p.k * p.Ci * p.Co * 2);
+    const int cpt = p.Co >> 6;
+    const int nk = Ty * Tx * cpt;
+    int avo[4];
+    int f_tap = -1, tapoff = 0;
+
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        const int t = kt / cpt, cc = kt - t * cpt;
+        if (t != f_tap) {
+            f_tap = t;
+            const int ty = t / Tx, tx = t - ty * Tx;
+            tapoff = ((cy + p.s * ty) * p.k + (cx + p.s * tx)) * p.Ci * p.Co * 2;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int oy = ay[n] - ty, ox = ax[n] - tx;
+                const bool ok = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+                avo[n] = ok ? (((ab[n] * p.Ho + oy) * p.Wo + ox) * p.Co + acs[n]) * 2 : OOB;
+            }
+        }
+        unsigned char* da = smem + buf * A_BYTES + (32 * wave) * ROWB;
+        unsigned char* db = smem + 2 * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
+#pragma unroll
+        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], tapoff + cc * 128, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + 2 * A_BYTES + cur * B_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+    }
+    store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Ci, p.Ci, p.dxp, p.pst, lane, [](float v, int) { return v; });
+#endif
+}
+
+template <class T>
+int launch_dgrad16s(const ConvGeom& g, DgSP p, hipStream_t st) {
+    const int BN = g.Ci % 128 == 0 ? 128 : 64;
+    p.tiles_n = g.Ci / BN;
+    p.nwg = cdiv(p.Mc, 128) * p.tiles_n;
+    if (BN == 128) hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 128>), dim3(p.nwg, 1, g.s * g.s), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 64>), dim3(p.nwg, 1, g.s * g.s), dim3(256), 0, st, p);
+    ACL_CHECK_LAUNCH("conv_dgrad16s_kernel");
+    return ACLGAN_OK;
+}
+
+// padded-grid gradient (storage pst) -> dx (storage dst): reflection_pad2d backward as an ordered gather, 4 channels per thread
+struct FoldSP { const void* dxp; void* dx; int B, Hi, Wi, Ci, Hp, Wp, p, accumulate, pst, dst; int64_t total; };
+
+__device__ __forceinline__ int fold_alias(int u, int n, int p, int* q) {     // padded positions q with reflect(q - p, n) == u
+    int c = 0;
+    q[c++] = u + p;
+    if (u >= 1 && u <= p) q[c++] = p - u;
+    if (u <= n - 2 && u >= n - 1 - p) q[c++] = p + 2 * (n - 1) - u;
+    return c;
+}
+__global__ void __launch_bounds__(256) conv_fold_st_kernel(FoldSP f) {
+    const int C4 = f.Ci >> 2;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < f.total; idx += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        int64_t pix = idx / C4;
+        const int j = (int)(pix % f.Wi); pix /= f.Wi;
+        const int i = (int)(pix % f.Hi);
+        const int b = (int)(pix / f.Hi);
+        int qy[3], qx[3];
+        const int ny = fold_alias(i, f.Hi, f.p, qy), nx = fold_alias(j, f.Wi, f.p, qx);
+        st_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e) acc += st_ld4(f.dxp, ((int64_t)(b * f.Hp + qy[a]) * f.Wp + qx[e]) * C4 + c4, f.pst);
+        if (f.accumulate) acc += st_ld4(f.dx, idx, f.dst);
+        st_st4(f.dx, idx, acc, f.dst);
+    }
+}
+
+bool shape_ok(const ConvGeom& g) {
+    return fast_enabled() && g.up == 0 && g.Ci % 64 == 0 && g.Co % 64 == 0 && g.k >= 1 && g.p < g.Hi && g.p < g.Wi;
+}
+bool enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_NOGLDS16"); v = (e && atoi(e)) ? 0 : 1; }
+    return v == 1;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// entry points
+// ------------------------------------------------------------------------------------------
+// which: 0 forward, 1 dgrad.  The forward also wants a grid that fills the chip without split-K (small late-discriminator maps keep the
+// split-K kernel of conv_fast16.hip, which reads the same 16-bit activations through its A16 path).
+bool conv16s_ok(const ConvGeom& g, int which) {
+    if (!enabled() || !shape_ok(g)) return false;
+    if (which == 0) {
+        const int BN = g.Co % 128 == 0 ? 128 : 64;
+        return cdiv(g.M, 128) * (g.Co / BN) >= 96 || g.K <= 1024;
+    }
+    return true;
+}
+
+int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st) {
+    if (!conv16s_ok(g, 0)) return ACLGAN_EUNSUPPORTED;
+    ACL_REQUIRE(x16 && w16 && y, "conv_fwd16s: null operand");
+    ACL_REQUIRE((long long)g.B * g.Hi * g.Wi * g.Ci * 2 < 0x7fffffe0ll && (long long)g.Co * g.K * 2 < 0x7fffffe0ll, "conv_fwd16s: operand beyond 2 GB");
+    FwdSP p;
+    p.x16 = (const u16*)x16; p.w16 = (const u16*)w16; p.bias = bias; p.y = y; p.yst = yst; p.stats = nullptr;
+    p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
+    p.M = g.M; p.K = g.K; p.act = g.act; p.tiles_n = 0; p.nwg = 0;
+    if (dtype == ACLGAN_DTYPE_BF16) return launch_fwd16s<QBF16>(g, p, st);
+    if (dtype == ACLGAN_DTYPE_FP16) return launch_fwd16s<QFP16>(g, p, st);
+    set_error("conv_fwd16s: dtype %d", dtype);
+    return ACLGAN_EINVAL;
+}
+
+size_t conv_dgrad16s_scratch_bytes(const ConvGeom& g) {
+    return conv16s_ok(g, 1) ? (((size_t)g.B * g.Hp * g.Wp * g.Ci * 2 + 255) & ~(size_t)255) : 0;
+}
+
+// dx (storage dxst) (+)= dgrad; scratch: conv_dgrad16s_scratch_bytes(g) (the padded-grid gradient, stored in the 16-bit dtype)
+int conv_dgrad16s(const ConvGeom& g, int dtype, const void* dy16, const void* w16t, void* dx, int dxst, int accumulate, void* scratch, hipStream_t st) {
+    if (!conv16s_ok(g, 1)) return ACLGAN_EUNSUPPORTED;
+    ACL_REQUIRE(dy16 && w16t && dx && scratch, "conv_dgrad16s: null operand / scratch");
+    ACL_REQUIRE((long long)g.B * g.Ho * g.Wo * g.Co * 2 < 0x7fffffe0ll && (long long)g.K * g.Co * 2 < 0x7fffffe0ll, "conv_dgrad16s: operand beyond 2 GB");
+    DgSP p;
+    p.dy16 = (const u16*)dy16; p.w16t = (const u16*)w16t; p.dxp = scratch; p.pst = dtype;
+    p.B = g.B; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.Ci = g.Ci; p.k = g.k; p.s = g.s; p.Hp = g.Hp; p.Wp = g.Wp;
+    p.Hc = cdiv(g.Hp, g.s); p.Wc = cdiv(g.Wp, g.s); p.Mc = g.B * p.Hc * p.Wc; p.tiles_n = 0; p.nwg = 0;
+    int rc;
+    if (dtype == ACLGAN_DTYPE_BF16) rc = launch_dgrad16s<QBF16>(g, p, st);
+    else if (dtype == ACLGAN_DTYPE_FP16) rc = launch_dgrad16s<QFP16>(g, p, st);
+    else { set_error("conv_dgrad16s: dtype %d", dtype); return ACLGAN_EINVAL; }
+    if (rc) return rc;
+    FoldSP f;
+    f.dxp = scratch; f.dx = dx; f.B = g.B; f.Hi = g.Hi; f.Wi = g.Wi; f.Ci = g.Ci; f.Hp = g.Hp; f.Wp = g.Wp; f.p = g.p;
+    f.accumulate = accumulate; f.pst = dtype; f.dst = dxst;
+    f.total = (int64_t)g.B * g.Hi * g.Wi * (g.Ci / 4);
+    hipLaunchKernelGGL(conv_fold_st_kernel, dim3((int)std::min<int64_t>(cdiv64(f.total, 256), 16384)), dim3(256), 0, st, f);
+    ACL_CHECK_LAUNCH("conv_fold_st_kernel");
+    return ACLGAN_OK;
+}
+
+}  // namespace aclgan

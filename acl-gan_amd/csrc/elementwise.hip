@@ -1,6 +1,7 @@
 // elementwise.hip -- the HBM-bound kernels of the ACL-GAN step (gfx950): normalisation layers
 // (+activation, +residual) forward/backward, pooling, focus blend, losses, Adam, small dense
-// layers, layout conversion.  All tensors fp32; activations NHWC ([B][HW][C]).
+// layers, layout conversion.  Activations NHWC ([B][HW][C]), stored fp32 or -- wide layers of the 16-bit compute dtypes -- bf16 / fp16
+// (st16.h: storage code per tensor, statistics / coefficients / arithmetic always fp32).
 //
 // Reference semantics restated here (file:line into the reference tree):
 //   InstanceNorm2d(affine=False)          networks.py:333   biased var, 1/sqrt(var+1e-5)
@@ -12,6 +13,7 @@
 //   LSGAN losses / L1                     networks.py:67,83,98 / trainer.py:61-62
 //   Adam (L2 weight decay)                trainer.py:39-42
 #include "common.h"
+#include "st16.h"
 
 namespace aclgan {
 
@@ -69,18 +71,18 @@ static int norm_chunk_pixels(int B, int HW) {
 
 // partial statistics: part[b][chunk][c] = (mean, M2) over the chunk's pixels.  Threads are laid
 // out C/4 float4-lanes wide (coalesced 16 B/lane along the channel axis), 256/(C/4) pixels deep.
-__global__ void __launch_bounds__(256) norm_stats_kernel(const float* __restrict__ x, float2* __restrict__ part,
+__global__ void __launch_bounds__(256) norm_stats_kernel(const void* __restrict__ x, int xst, float2* __restrict__ part,
                                                          int HW, int C, int chunk, int nchunks) {
     const int C4 = C >> 2;
     const int b = blockIdx.y, ch = blockIdx.x;
     const int p0 = ch * chunk, p1 = min(HW, p0 + chunk);
     const int cg = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
-    const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * HW * C);
+    const int64_t xb = (int64_t)b * HW * C4;
     // shift = the chunk's first pixel (kills the cancellation in sumsq - sum^2/n)
-    const float4 sh = xb[(size_t)p0 * C4 + cg];
+    const st_f32x4 sh = st_ld4(x, xb + (int64_t)p0 * C4 + cg, xst);
     float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
     for (int p = p0 + pl; p < p1; p += PL) {
-        const float4 v = xb[(size_t)p * C4 + cg];
+        const st_f32x4 v = st_ld4(x, xb + (int64_t)p * C4 + cg, xst);
         const float dx = v.x - sh.x, dy = v.y - sh.y, dz = v.z - sh.z, dw = v.w - sh.w;
         s.x += dx; s.y += dy; s.z += dz; s.w += dw;
         q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
@@ -192,21 +194,21 @@ __global__ void __launch_bounds__(256) norm_finalize_ln_kernel(const float2* __r
 }
 
 // y = act(x*scale[b][c] + shift[b][c]) (+ residual)
-__global__ void __launch_bounds__(256) norm_apply_kernel(const float4* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const float4* __restrict__ res,
-                                                         float4* __restrict__ y, int HW, int C, int act, int64_t total4) {
+__global__ void __launch_bounds__(256) norm_apply_kernel(const void* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const void* __restrict__ res,
+                                                         void* __restrict__ y, NormST st, int HW, int C, int act, int64_t total4) {
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int cg = (int)(i % C4);
         const int b = (int)(i / ((int64_t)HW * C4));
         const float4 sc = *reinterpret_cast<const float4*>(scale + b * C + cg * 4);
         const float4 sh = *reinterpret_cast<const float4*>(shift + b * C + cg * 4);
-        const float4 v = x[i];
-        float4 o;
+        const st_f32x4 v = st_ld4(x, i, st.x);
+        st_f32x4 o;
         o.x = act_fwd(fmaf(v.x, sc.x, sh.x), act); o.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
         o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act); o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
-        if (res) { const float4 r = res[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-        y[i] = o;
+        if (res) { const st_f32x4 r = st_ld4(res, i, st.res); o += r; }
+        st_st4(y, i, o, st.y);
     }
 }
 
@@ -220,8 +222,10 @@ size_t norm_scratch_bytes(int B, int HW, int C) {
 
 // stats != nullptr: the producer of x already wrote the chunk partials [B][HW / stats_chunk][C] (mean, M2) -- conv_fwd's epilogue
 // (conv_fwd_stats_chunk) -- and the statistics pass over x is skipped
-int norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const float* w, const float* b, int w_stride,
-             const float* residual, float* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats, int stats_chunk) {
+int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float* w, const float* b, int w_stride,
+             const void* residual, void* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats, int stats_chunk,
+             const NormST* sto) {
+    const NormST sd = sto ? *sto : NormST();
     ACL_REQUIRE(pow2(C) && C >= 4 && C <= 1024, "norm: C=%d must be a power of two in [4,1024]", C);
     ACL_REQUIRE(kind == ACLGAN_NORM_IN || kind == ACLGAN_NORM_ADAIN || kind == ACLGAN_NORM_LN, "norm: bad kind %d", kind);
     ACL_REQUIRE(!(residual && act != ACLGAN_ACT_NONE), "norm: residual requires act none");
@@ -232,7 +236,7 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const floa
     float* scale = (float*)((float2*)scratch + (size_t)B * cdiv(HW, own_chunk) * C);
     float* shift = scale + (size_t)B * C;
     if (!stats) {
-        hipLaunchKernelGGL(norm_stats_kernel, dim3(nchunks, B), dim3(256), 0, st, x, part, HW, C, chunk, nchunks);
+        hipLaunchKernelGGL(norm_stats_kernel, dim3(nchunks, B), dim3(256), 0, st, x, sd.x, part, HW, C, chunk, nchunks);
         ACL_CHECK_LAUNCH("norm_stats_kernel");
     }
     if (kind == ACLGAN_NORM_LN) {
@@ -248,8 +252,7 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const floa
     ACL_CHECK_LAUNCH("norm_finalize");
     const int64_t total4 = (int64_t)B * HW * C / 4;
     const int grid = (int)std::min<int64_t>(cdiv64(total4, 256), 8192);
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(grid), dim3(256), 0, st, (const float4*)x, scale, shift, (const float4*)residual,
-                       (float4*)y, HW, C, act, total4);
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(grid), dim3(256), 0, st, x, scale, shift, residual, y, sd, HW, C, act, total4);
     ACL_CHECK_LAUNCH("norm_apply_kernel");
     return ACLGAN_OK;
 }
@@ -264,8 +267,8 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const float* x, const floa
 //             dx = t*(dxhat - S1_b/n) - xhat*S2_b/((n-1)*std);  dgamma_c += sum_b s2;  dbeta_c += sum_b s1
 //   both written as dx = A[b][c]*g + Bc[b][c]*xhat + Cc[b][c]
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                              const float* __restrict__ dy, const float* __restrict__ mean,
+__global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __restrict__ x, const void* __restrict__ y,
+                                                              const void* __restrict__ dy, NormST st, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int per_channel_stats,
                                                               float2* __restrict__ part, int HW, int C, int chunk,
                                                               int nchunks, int act) {
@@ -273,10 +276,7 @@ __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const float* __res
     const int b = blockIdx.y, ch = blockIdx.x;
     const int p0 = ch * chunk, p1 = min(HW, p0 + chunk);
     const int cg = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
-    const size_t base = (size_t)b * HW * C4;
-    const float4* xb = reinterpret_cast<const float4*>(x) + base;
-    const float4* yb = reinterpret_cast<const float4*>(y) + base;
-    const float4* gb = reinterpret_cast<const float4*>(dy) + base;
+    const int64_t base = (int64_t)b * HW * C4;
     float4 mu, rs;
     if (per_channel_stats) {
         mu = *reinterpret_cast<const float4*>(mean + b * C + cg * 4);
@@ -287,10 +287,10 @@ __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const float* __res
     }
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     for (int p = p0 + pl; p < p1; p += PL) {
-        const size_t i = (size_t)p * C4 + cg;
-        const float4 xv = xb[i], gv = gb[i];
-        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (act != ACLGAN_ACT_NONE) yv = yb[i];            // act-less norms (2nd norm of every ResBlock): y is not needed, skip its HBM read
+        const int64_t i = base + (int64_t)p * C4 + cg;
+        const st_f32x4 xv = st_ld4(x, i, st.x), gv = st_ld4(dy, i, st.dy);
+        st_f32x4 yv = {1.f, 1.f, 1.f, 1.f};
+        if (act != ACLGAN_ACT_NONE) yv = st_ld4(y, i, st.y);   // act-less norms (2nd norm of every ResBlock): y is not needed, skip its HBM read
         const float g0 = gv.x * act_grad(yv.x, act), g1 = gv.y * act_grad(yv.y, act);
         const float g2 = gv.z * act_grad(yv.z, act), g3 = gv.w * act_grad(yv.w, act);
         s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
@@ -407,12 +407,12 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_ln_kernel(const float2*
     }
 }
 
-__global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
-                                                             const float4* __restrict__ dy, const float* __restrict__ mean,
+__global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ y,
+                                                             const void* __restrict__ dy, NormST st, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int per_channel_stats,
                                                              const float* __restrict__ cA, const float* __restrict__ cB,
-                                                             const float* __restrict__ cC, float4* __restrict__ dx,
-                                                             float4* __restrict__ dres, int dres_acc, int HW, int C, int act,
+                                                             const float* __restrict__ cC, void* __restrict__ dx,
+                                                             void* __restrict__ dres, int dres_acc, int HW, int C, int act,
                                                              int64_t total4) {
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
@@ -429,28 +429,29 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const float4* __res
         const float4 a = *reinterpret_cast<const float4*>(cA + o);
         const float4 kb = *reinterpret_cast<const float4*>(cB + o);
         const float4 kc = *reinterpret_cast<const float4*>(cC + o);
-        const float4 xv = x[i], gv = dy[i];
-        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (act != ACLGAN_ACT_NONE) yv = y[i];
-        float4 g;
+        const st_f32x4 xv = st_ld4(x, i, st.x), gv = st_ld4(dy, i, st.dy);
+        st_f32x4 yv = {1.f, 1.f, 1.f, 1.f};
+        if (act != ACLGAN_ACT_NONE) yv = st_ld4(y, i, st.y);
+        st_f32x4 g;
         g.x = gv.x * act_grad(yv.x, act); g.y = gv.y * act_grad(yv.y, act);
         g.z = gv.z * act_grad(yv.z, act); g.w = gv.w * act_grad(yv.w, act);
-        float4 d;
+        st_f32x4 d;
         d.x = fmaf(a.x, g.x, fmaf(kb.x, (xv.x - mu.x) * rs.x, kc.x));
         d.y = fmaf(a.y, g.y, fmaf(kb.y, (xv.y - mu.y) * rs.y, kc.y));
         d.z = fmaf(a.z, g.z, fmaf(kb.z, (xv.z - mu.z) * rs.z, kc.z));
         d.w = fmaf(a.w, g.w, fmaf(kb.w, (xv.w - mu.w) * rs.w, kc.w));
-        dx[i] = d;
+        st_st4(dx, i, d, st.dx);
         if (dres) {
-            if (dres_acc) { const float4 r = dres[i]; g.x += r.x; g.y += r.y; g.z += r.z; g.w += r.w; }
-            dres[i] = g;
+            if (dres_acc) g += st_ld4(dres, i, st.dres);
+            st_st4(dres, i, g, st.dres);
         }
     }
 }
 
-int norm_bwd(int kind, int act, int B, int HW, int C, const float* x, const float* y, const float* dy, const float* w,
-             int w_stride, const float* mean, const float* rstd, float* dx, float* dw, float* db, float* dres,
-             int dres_accumulate, void* scratch, hipStream_t st) {
+int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy, const float* w,
+             int w_stride, const float* mean, const float* rstd, void* dx, float* dw, float* db, void* dres,
+             int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto) {
+    const NormST sd = sto ? *sto : NormST();
     ACL_REQUIRE(pow2(C) && C >= 4 && C <= 1024, "norm: C=%d must be a power of two in [4,1024]", C);
     const int chunk = norm_chunk_pixels(B, HW), nchunks = cdiv(HW, chunk);
     float2* part = (float2*)scratch;
@@ -458,7 +459,7 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const float* x, const floa
     float* cB = cA + (size_t)B * C;
     float* cC = cB + (size_t)B * C;
     const int pcs = kind != ACLGAN_NORM_LN;
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(nchunks, B), dim3(256), 0, st, x, y, dy, mean, rstd, pcs, part, HW, C, chunk,
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(nchunks, B), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, part, HW, C, chunk,
                        nchunks, act);
     ACL_CHECK_LAUNCH("norm_bwd_reduce_kernel");
     if (kind == ACLGAN_NORM_LN) {
@@ -478,8 +479,8 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const float* x, const floa
     }
     const int64_t total4 = (int64_t)B * HW * C / 4;
     const int grid = (int)std::min<int64_t>(cdiv64(total4, 256), 8192);
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, (const float4*)x, (const float4*)y, (const float4*)dy, mean,
-                       rstd, pcs, cA, cB, cC, (float4*)dx, (float4*)dres, dres_accumulate, HW, C, act, total4);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, cA, cB, cC, dx, dres, dres_accumulate,
+                       HW, C, act, total4);
     ACL_CHECK_LAUNCH("norm_bwd_apply_kernel");
     return ACLGAN_OK;
 }

@@ -43,10 +43,13 @@ struct Group {
     float *param = nullptr, *grad = nullptr, *m = nullptr, *v = nullptr;
 };
 
-// activation tensor, NHWC
+// activation tensor, NHWC.  Storage (st16.h): dt = dtype of d, gdt = dtype of g -- 0: fp32; else the context's 16-bit compute dtype,
+// in which case d / g address 16-bit data (the float* type is kept for the fp32 kernels' signatures).  g always OWNS 4 bytes per
+// element: its dtype is settled only when the forward is complete (a consumer whose backward writes fp32 clears gdt).
 struct Act {
     float* d = nullptr;
     float* g = nullptr;
+    int dt = 0, gdt = 0;
     int B = 0, H = 0, W = 0, C = 0;
     bool need_grad = false;
     bool gw = false;   // gradient buffer holds valid data (first writer overwrites, later ones accumulate)
@@ -107,6 +110,11 @@ struct aclgan_ctx {
     double alg_bytes = 0.0;
     void count(double bytes) { alg_bytes += bytes; }
     size_t keep_total = 0;      // bytes of Winograd input transforms kept for the weight gradients of this update (conv_block)
+    // 16-bit activation / gradient storage of the wide layers (C % 64 == 0) under a 16-bit compute dtype; co16: also the conv outputs
+    // that feed a normalisation layer (ACLGAN_ACT16=0 / ACLGAN_CO16=0|1 switch them)
+    bool act16() const { return dtype != ACLGAN_DTYPE_FP32 && act16_enabled(); }
+    static bool act16_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ACLGAN_ACT16"); v = (e && !atoi(e)) ? 0 : 1; } return v == 1; }
+    static bool co16_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ACLGAN_CO16"); v = e ? (atoi(e) ? 1 : 0) : 1; } return v == 1; }
 
     ~aclgan_ctx() { reset_step(); }
     void reset_step() {
@@ -125,10 +133,11 @@ struct aclgan_ctx {
         return ws + a;
     }
     float* allocf(int64_t n) { return (float*)alloc((size_t)n * sizeof(float)); }
-    Act* new_act(int B, int H, int W, int C, bool need_grad) {
+    // st != 0: d (and, until a consumer objects, g) stored in the 16-bit compute dtype
+    Act* new_act(int B, int H, int W, int C, bool need_grad, int st = 0) {
         Act* a = new Act();
-        a->B = B; a->H = H; a->W = W; a->C = C; a->need_grad = need_grad;
-        a->d = allocf(a->numel());
+        a->B = B; a->H = H; a->W = W; a->C = C; a->need_grad = need_grad; a->dt = st; a->gdt = st;
+        a->d = (float*)alloc((size_t)a->numel() * (st ? 2 : 4));
         if (need_grad) a->g = allocf(a->numel());
         acts.push_back(a);
         return a;
@@ -137,6 +146,7 @@ struct aclgan_ctx {
     Act* new_view(Act* joint, int b0, int nb) {
         Act* a = new Act();
         a->B = nb; a->H = joint->H; a->W = joint->W; a->C = joint->C; a->need_grad = joint->need_grad;
+        // (views exist only of the fp32 joint discriminator inputs)
         const int64_t off = (int64_t)b0 * joint->H * joint->W * joint->C;
         a->d = joint->d + off;
         a->g = joint->g ? joint->g + off : nullptr;
@@ -286,8 +296,15 @@ struct NormSpec {
 static inline void mark_written(Act* a) { a->gw = true; }
 
 // Conv2dBlock.forward (networks.py:365-371) [+ preceding nn.Upsample, + ResBlock residual add]
+//
+// Storage under a 16-bit compute dtype (round 3; ctx.act16()): the block's output is stored in the 16-bit dtype when it is wide
+// (Co % 64 == 0) and the caller says its consumers read 16-bit (out16: everything except the input of the 7x7 image-side output layer);
+// the conv output in front of a normalisation layer likewise when the 16-bit-storage kernels run it (conv16s_ok, ctx.co16).  Gradients:
+// d(out) follows out unless a consumer's input-gradient kernel can only write fp32 (the sub-pixel layers); d(conv output) is 16-bit
+// exactly when this layer's backward runs on the 16-bit-storage kernels.  Kernels that take only fp32 never see a 16-bit tensor: the
+// rules below keep it so, and every launch site checks.
 static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co, int k, int stride, int pad, int up, int act,
-                      const NormSpec& ns, Act* residual, Act** out_p) {
+                      const NormSpec& ns, Act* residual, Act** out_p, int out16 = 1) {
     aclgan_conv_desc d;
     d.B = in->B; d.Hi = in->H; d.Wi = in->W; d.Ci = in->C; d.Co = Co; d.k = k; d.stride = stride; d.pad = pad; d.upsample = up;
     d.act = ns.kind == ACLGAN_NORM_NONE ? act : ACLGAN_ACT_NONE;
@@ -295,22 +312,37 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     CHK(make_geom(&d, &g));
     if (!W.w) { set_error("conv_block: parameters not bound"); return ACLGAN_EINVAL; }
     const bool want_grad = train_w || in->need_grad || ns.dw != nullptr;
-    Act* co = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad);
-    NEED(co->d); if (want_grad) NEED(co->g);
+    const bool has_norm = ns.kind != ACLGAN_NORM_NONE;
     // 16-bit MFMA path (compute dtype bf16 / fp16): per operator, whenever the shape has a 16-bit kernel
     const int dt = c.dtype;
     const bool h16 = dt != ACLGAN_DTYPE_FP32 && W.w16 != nullptr;
     const bool f16 = h16 && conv16_eligible(g, 0), d16 = h16 && conv16_eligible(g, 1), w16 = h16 && conv16_eligible(g, 2);
+    const bool a16 = h16 && c.act16();
+    const bool s_bwd = a16 && f16 && d16 && w16 && conv16s_ok(g, 1);                 // backward on the 16-bit-storage kernels
+    const bool s_fwd = a16 && f16 && conv16s_ok(g, 0) && in->dt != 0;                 // forward on the LDS-DMA kernel
+    if (in->dt != 0 && !f16) { set_error("conv_block: a 16-bit activation reached a layer without a 16-bit kernel (Cin %d, Cout %d, k %d)", g.Ci, g.Co, g.k); return ACLGAN_EINVAL; }
+    const int out_st = (a16 && Co % 64 == 0 && out16) ? dt : 0;
+    const int co_st = has_norm ? ((s_bwd && aclgan_ctx::co16_enabled()) ? dt : 0) : ((f16 || !out_st) ? out_st : 0);
+    Act* co = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad, co_st);
+    NEED(co->d); if (want_grad) NEED(co->g);
     Act* out = co;
     float *mean = nullptr, *rstd = nullptr;
     const int HW = g.Ho * g.Wo;
-    if (ns.kind != ACLGAN_NORM_NONE) {
-        out = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad);
+    if (has_norm) {
+        out = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad, out_st);
         NEED(out->d); if (want_grad) NEED(out->g);
         const int nstat = ns.kind == ACLGAN_NORM_LN ? g.B : g.B * Co;
         mean = c.allocf(nstat); rstd = c.allocf(nstat);
         NEED(mean); NEED(rstd);
+        co->gdt = s_bwd ? dt : 0;             // read by this layer's dgrad / wgrad kernels
+    } else if (out_st && !co_st) {            // an fp32-only kernel (image-side first layers) feeding 16-bit consumers: one conversion pass
+        out = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad, out_st);
+        NEED(out->d); if (want_grad) NEED(out->g);
+        out->gdt = 0;                         // this layer's backward kernels read fp32
+    } else {
+        out->gdt = s_bwd ? co_st : 0;         // (fp32 d with 16-bit-storage backward kernels: converted out of place in the backward)
     }
+    if (in->need_grad && !s_bwd) in->gdt = 0;   // this layer's input-gradient kernels write fp32
     // Winograd layers: the forward's input transform V = B^T x B is exactly what the weight gradient needs again -- keep it (persistent
     // until the tape has run: 75 MB per ResBlock convolution at 256x256 B=8, ~6 GB per update) instead of recomputing it
     // Bounded: the kept transforms of one update may take at most keepv_budget() bytes of the arena (default 64 GB of the 288 GB; 256x256
@@ -320,26 +352,32 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         const size_t kb = conv_fwd_keep_bytes(g);
         if (kb && c.keep_total + kb <= keepv_budget()) { keepV = (float*)c.alloc(kb); NEED(keepV); c.keep_total += kb; }
     }
-    c.count(4.0 * ((double)in->numel() + (double)Co * g.K + Co + (double)co->numel()));                          // conv: x, w, bias -> y
-    if (ns.kind != ACLGAN_NORM_NONE) c.count(4.0 * (2.0 * (double)co->numel() + (residual ? (double)co->numel() : 0.0)));   // norm+act(+residual): y -> out
+    const double es_in = in->dt ? 2.0 : 4.0, es_co = co->dt ? 2.0 : 4.0, es_out = out->dt ? 2.0 : 4.0, es_w = f16 ? 2.0 : 4.0;
+    c.count(es_in * (double)in->numel() + es_w * (double)Co * g.K + 4.0 * Co + es_co * (double)co->numel());             // conv: x, w, bias -> y
+    if (out != co) c.count((es_co + es_out) * (double)co->numel() + ((has_norm && residual) ? (residual->dt ? 2.0 : 4.0) * (double)co->numel() : 0.0));   // norm+act(+residual) / conversion: y -> out
     const size_t mark = c.top;
     // normalisation statistics from the conv epilogue where the forward kernel offers them (Winograd output transform)
-    const int schunk = (ns.kind != ACLGAN_NORM_NONE && !f16) ? conv_fwd_stats_chunk(g) : 0;
+    const int schunk = (has_norm && !f16) ? conv_fwd_stats_chunk(g) : 0;
     float* stats = nullptr;
     if (schunk) { stats = c.allocf((size_t)2 * g.B * (HW / schunk) * Co); NEED(stats); }
     {
         const size_t fmark = c.top;
         void* fscr = nullptr;
-        const size_t fb = f16 ? conv_fwd16_scratch_bytes(g) : conv_fwd_scratch_bytes(g);   // merged phase weights (upsample + 5x5 layers), split-K partials
+        const size_t fb = s_fwd ? 0 : (f16 ? conv_fwd16_scratch_bytes(g) : conv_fwd_scratch_bytes(g));   // merged phase weights (upsample + 5x5 layers), split-K partials
         if (fb) { fscr = c.alloc(fb); NEED(fscr); }
-        if (f16) RUN(conv_fwd16(g, dt, in->d, W.w, W.w16, W.b, co->d, fscr, c.st));
+        if (s_fwd) RUN(conv_fwd16s(g, dt, in->d, W.w16, W.b, co->d, co->dt, c.st));
+        else if (f16) RUN(conv_fwd16(g, dt, in->dt ? nullptr : in->d, W.w, W.w16, W.b, co->d, fscr, c.st, in->dt ? in->d : nullptr, co->dt));
         else RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr, stats, keepV));
         c.top = fmark;
     }
-    if (ns.kind != ACLGAN_NORM_NONE) {
+    NormST nst;
+    nst.x = co->dt; nst.y = out->dt; nst.res = residual ? residual->dt : 0;
+    if (has_norm) {
         void* scr = c.alloc(norm_scratch_bytes(g.B, HW, Co));
         NEED(scr);
-        RUN(norm_fwd(ns.kind, act, g.B, HW, Co, co->d, ns.w, ns.b, ns.w_stride, residual ? residual->d : nullptr, out->d, mean, rstd, scr, c.st, stats, schunk));
+        RUN(norm_fwd(ns.kind, act, g.B, HW, Co, co->d, ns.w, ns.b, ns.w_stride, residual ? residual->d : nullptr, out->d, mean, rstd, scr, c.st, stats, schunk, &nst));
+    } else if (out != co) {
+        RUN(cast_storage(co->d, co->dt, out->d, out->dt, co->numel(), c.st));
     }
     c.top = mark;
     *out_p = out;
@@ -350,38 +388,65 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         aclgan_ctx& c = *cp;
         if (!out->gw) return ACLGAN_OK;   // no gradient reached this block
         // backward of norm / activation: x (or y), dy -> dx (+ dres); wgrad: x, dy -> dw, db; dgrad: dy, w -> dx
-        c.count(4.0 * (3.0 * (double)co->numel() + ((residual && residual->need_grad) ? (double)co->numel() : 0.0)));
-        if (train_w) c.count(4.0 * ((double)in->numel() + (double)co->numel() + (double)Co * g.K + Co));
-        if (in->need_grad) c.count(4.0 * ((double)co->numel() + (double)Co * g.K + (double)in->numel()));
-        if (ns.kind != ACLGAN_NORM_NONE) {
+        const double eg_out = out->gdt ? 2.0 : 4.0, eg_co = (has_norm ? co->gdt : (s_bwd ? dt : out->gdt)) ? 2.0 : 4.0, eg_in = in->gdt ? 2.0 : 4.0;
+        c.count((es_co + eg_out + eg_co) * (double)co->numel() + ((residual && residual->need_grad) ? (residual->gdt ? 2.0 : 4.0) * (double)co->numel() : 0.0));
+        if (train_w) c.count(es_in * (double)in->numel() + eg_co * (double)co->numel() + 4.0 * ((double)Co * g.K + Co));
+        if (in->need_grad) c.count(eg_co * (double)co->numel() + es_w * (double)Co * g.K + eg_in * (double)in->numel());
+        const size_t mark0 = c.top;
+        const float* dyp = nullptr;       // gradient w.r.t. the conv output, as the dgrad / wgrad kernels read it
+        int dy_st = 0;
+        if (has_norm) {
             const size_t mark = c.top;
             void* scr = c.alloc(norm_scratch_bytes(g.B, HW, Co));
             NEED(scr);
             float* dres = nullptr; int dacc = 0;
             if (residual && residual->need_grad) { dres = residual->g; dacc = residual->gw ? 1 : 0; mark_written(residual); }
-            RUN(norm_bwd(ns.kind, act, g.B, HW, Co, co->d, out->d, out->g, ns.w, ns.w_stride, mean, rstd, co->g, ns.dw, ns.db, dres, dacc, scr, c.st));
+            NormST bst;
+            bst.x = co->dt; bst.y = out->dt; bst.dy = out->gdt; bst.dx = co->gdt; bst.dres = residual ? residual->gdt : 0;
+            RUN(norm_bwd(ns.kind, act, g.B, HW, Co, co->d, out->d, out->g, ns.w, ns.w_stride, mean, rstd, co->g, ns.dw, ns.db, dres, dacc, scr, c.st, &bst));
             c.top = mark;
+            dyp = co->g; dy_st = co->gdt;
+        } else if (s_bwd && out->gdt == 0) {
+            // the consumers delivered an fp32 gradient, this layer's backward kernels read 16-bit: dy16 = act'(y) * dy, out of place
+            float* g16 = (float*)c.alloc((size_t)out->numel() * 2);
+            NEED(g16);
+            RUN(cast_storage(out->g, 0, g16, dt, out->numel(), c.st));
+            RUN(act_bwd_inplace(act, out->d, g16, out->numel(), c.st, out->dt, dt));
+            dyp = g16; dy_st = dt;
         } else {
-            RUN(act_bwd_inplace(act, co->d, co->g, co->numel(), c.st));   // out == co
+            RUN(act_bwd_inplace(act, co->d, out->g, out->numel(), c.st, co->dt, out->gdt));   // (co != out: the fp32 copy of the same values)
+            dyp = out->g; dy_st = out->gdt;
         }
         if (train_w) {
             const size_t mark = c.top;
             void* wscr = nullptr;
             const size_t wb = w16 ? conv_wgrad16_scratch_bytes(g) : conv_wgrad_scratch_bytes(g);
             if (wb) { wscr = c.alloc(wb); NEED(wscr); }
-            if (w16) RUN(conv_wgrad16(g, dt, in->d, co->g, W.dw, W.db, wscr, c.st));
-            else RUN(conv_wgrad(g, in->d, co->g, W.dw, W.db, c.st, wscr, keepV));
+            if (w16) RUN(conv_wgrad16(g, dt, in->d, dyp, W.dw, W.db, wscr, c.st, in->dt, dy_st));
+            else {
+                if (in->dt || dy_st) { set_error("conv_block: fp32 weight-gradient kernel on 16-bit operands"); return ACLGAN_EINVAL; }
+                RUN(conv_wgrad(g, in->d, dyp, W.dw, W.db, c.st, wscr, keepV));
+            }
             c.top = mark;
         }
         if (in->need_grad) {
             const size_t mark = c.top;
-            void* scr = c.alloc(d16 ? conv_dgrad16_scratch_bytes(g) + 256 : conv_dgrad_scratch_bytes(g));
-            NEED(scr);
-            if (d16) RUN(conv_dgrad16(g, dt, co->g, W.w, W.w16t, in->g, in->gw ? 1 : 0, scr, c.st));
-            else RUN(conv_dgrad(g, co->g, W.w, in->g, scr, in->gw ? 1 : 0, c.st));
+            if (s_bwd) {
+                if (!dy_st) { set_error("conv_block: 16-bit-storage dgrad on an fp32 gradient"); return ACLGAN_EINVAL; }
+                void* scr = c.alloc(conv_dgrad16s_scratch_bytes(g));
+                NEED(scr);
+                RUN(conv_dgrad16s(g, dt, dyp, W.w16t, in->g, in->gdt, in->gw ? 1 : 0, scr, c.st));
+            } else {
+                if (dy_st || in->gdt) { set_error("conv_block: fp32-output dgrad kernel on 16-bit gradients"); return ACLGAN_EINVAL; }
+                void* scr = c.alloc(d16 ? conv_dgrad16_scratch_bytes(g) + 256 : conv_dgrad_scratch_bytes(g));
+                NEED(scr);
+                if (d16) RUN(conv_dgrad16(g, dt, dyp, W.w, W.w16t, in->g, in->gw ? 1 : 0, scr, c.st));
+                else RUN(conv_dgrad(g, dyp, W.w, in->g, scr, in->gw ? 1 : 0, c.st));
+            }
             mark_written(in);
             c.top = mark;
         }
+        c.top = mark0;
         return ACLGAN_OK;
     }, {{train_w ? W.dw : nullptr, W.nw}, {train_w ? W.db : nullptr, W.nb}, {ln_train ? ns.dw : nullptr, Co}, {ln_train ? ns.db : nullptr, Co}});
     return ACLGAN_OK;
@@ -468,15 +533,15 @@ static int style_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
     const bool want = h->need_grad;
     Act* p = c.new_act(h->B, 1, 1, d, want);
     NEED(p->d); if (want) NEED(p->g);
-    RUN(gap_fwd(h->B, h->H * h->W, d, h->d, p->d, c.st));
-    c.count(4.0 * (double)h->numel() * (want ? 2.0 : 1.0));
+    RUN(gap_fwd(h->B, h->H * h->W, d, h->d, p->d, c.st, h->dt));
+    c.count((h->dt ? 2.0 : 4.0) * (double)h->numel() * (want ? 2.0 : 1.0));
     if (want) {
         aclgan_ctx* cp = &c;
         Act* hh = h;
         c.push([=]() -> int {
             aclgan_ctx& c = *cp;
             if (!p->gw) return ACLGAN_OK;
-            RUN(gap_bwd(hh->B, hh->H * hh->W, hh->C, p->g, hh->g, hh->gw ? 1 : 0, c.st));
+            RUN(gap_bwd(hh->B, hh->H * hh->W, hh->C, p->g, hh->g, hh->gw ? 1 : 0, c.st, hh->gdt));
             mark_written(hh);
             return ACLGAN_OK;
         });
@@ -522,7 +587,8 @@ static int decode(aclgan_ctx& c, int net, bool train, Act* content, Act* style, 
         snprintf(buf, sizeof buf, "dec.model.%d.norm.gamma", idx); ns.w = c.param(0, net, buf); ns.dw = train ? c.gradp(0, net, buf) : nullptr;
         snprintf(buf, sizeof buf, "dec.model.%d.norm.beta", idx); ns.b = c.param(0, net, buf); ns.db = train ? c.gradp(0, net, buf) : nullptr;
         snprintf(buf, sizeof buf, "dec.model.%d.conv", idx);
-        CHK(conv_block(c, c.pw(0, net, buf), train, h, d / 2, 5, 1, 2, 1, ACLGAN_ACT_RELU, ns, nullptr, &h));
+        // (the last of these feeds the fp32 7x7 image-side output layer: its output stays fp32)
+        CHK(conv_block(c, c.pw(0, net, buf), train, h, d / 2, 5, 1, 2, 1, ACLGAN_ACT_RELU, ns, nullptr, &h, i + 1 < a.gen_n_downsample ? 1 : 0));
         d /= 2; idx += 2;
     }
     NormSpec none;
@@ -543,7 +609,8 @@ static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<A
         for (int i = 0; i < a.dis_n_layer; ++i) {
             snprintf(buf, sizeof buf, "cnns.%d.%d.conv", s, i);
             const int co = i == 0 ? d : 2 * d;
-            CHK(conv_block(c, c.pw(1, net, buf), train, h, co, 4, 2, 1, 0, ACLGAN_ACT_LRELU, none, nullptr, &h));
+            // (the last layer of a scale feeds the fp32 1x1 head: its output stays fp32)
+            CHK(conv_block(c, c.pw(1, net, buf), train, h, co, 4, 2, 1, 0, ACLGAN_ACT_LRELU, none, nullptr, &h, i + 1 < a.dis_n_layer ? 1 : 0));
             if (i > 0) d *= 2;
         }
         snprintf(buf, sizeof buf, "cnns.%d.%d", s, a.dis_n_layer);
@@ -1007,6 +1074,7 @@ int aclgan_forward_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t*
         if (which == 0) {
             rc = input_act(c, nullptr, B, 3, H, W, &x);
             if (!rc) rc = content_encode(c, ACLGAN_NET_GEN_AB, false, x, &o);
+            if (!rc && o && o->dt) c.allocf(o->numel());      // fp32 copy of a 16-bit content code (aclgan_gen_encode)
             if (!rc) rc = style_encode(c, ACLGAN_NET_GEN_AB, false, x, &s);
         } else if (which == 1) {
             rc = input_act(c, nullptr, B, C, std::max(1, H / q), std::max(1, W / q), &x);
@@ -1122,7 +1190,16 @@ int aclgan_gen_encode(aclgan_ctx* ctx, int net, const float* x, int B, int H, in
     if (rc) return rc;
     Act *xa = nullptr, *cc = nullptr, *ss = nullptr;
     rc = input_act(c, x, B, 3, H, W, &xa);
-    if (!rc && content) { rc = content_encode(c, net, false, xa, &cc); if (!rc) rc = nhwc_to_nchw(cc->d, content, cc->B, cc->C, cc->H, cc->W, c.st); }
+    if (!rc && content) {
+        rc = content_encode(c, net, false, xa, &cc);
+        const float* src = cc ? cc->d : nullptr;
+        if (!rc && cc->dt) {      // the content code lives in HBM in the 16-bit dtype: the public surface hands out fp32 (test.py:58-70)
+            float* tmp = c.allocf(cc->numel());
+            if (!tmp) { set_error("workspace too small"); rc = ACLGAN_ENOMEM; }
+            else { rc = cast_storage(cc->d, cc->dt, tmp, 0, cc->numel(), c.st); src = tmp; }
+        }
+        if (!rc) rc = nhwc_to_nchw(src, content, cc->B, cc->C, cc->H, cc->W, c.st);
+    }
     if (!rc && style) {
         rc = style_encode(c, net, false, xa, &ss);
         if (!rc) { hipError_t e = hipMemcpyAsync(style, ss->d, sizeof(float) * ss->numel(), hipMemcpyDeviceToDevice, c.st); if (e != hipSuccess) rc = hip_fail(e, "copy style"); }

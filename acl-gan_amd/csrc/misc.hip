@@ -1,6 +1,7 @@
 // misc.hip -- small HBM-bound / latency-bound kernels of the ACL-GAN step (gfx950):
 // pooling, focus blend, losses (wavefront-shuffle reductions), Adam, dense layers, GAP, layout.
 #include "common.h"
+#include "st16.h"
 
 namespace aclgan {
 
@@ -37,11 +38,39 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, float* __restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         dy[i] *= act_grad_m(y[i], act);
 }
-int act_bwd_inplace(int act, const float* y, float* dy, int64_t n, hipStream_t st) {
+// the same on tensors of any storage dtype (st16.h), four elements per thread
+__global__ void act_bwd_st_kernel(const void* __restrict__ y, int yst, void* __restrict__ dy, int gst, int act, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const st_f32x4 yv = st_ld4(y, i, yst);
+        st_f32x4 g = st_ld4(dy, i, gst);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= act_grad_m(yv[e], act);
+        st_st4(dy, i, g, gst);
+    }
+}
+int act_bwd_inplace(int act, const void* y, void* dy, int64_t n, hipStream_t st, int yst, int gst) {
     if (act == ACLGAN_ACT_NONE || n == 0) return ACLGAN_OK;
-    const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 8192);
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, st, y, dy, act, n);
-    ACL_CHECK_LAUNCH("act_bwd_kernel");
+    if (yst == ST_F32 && gst == ST_F32) {
+        const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 8192);
+        hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, st, (const float*)y, (float*)dy, act, n);
+        ACL_CHECK_LAUNCH("act_bwd_kernel");
+        return ACLGAN_OK;
+    }
+    ACL_REQUIRE(n % 4 == 0, "act_bwd: %lld elements of a 16-bit tensor (must be a multiple of 4)", (long long)n);
+    hipLaunchKernelGGL(act_bwd_st_kernel, dim3((int)std::min<int64_t>(cdiv64(n / 4, 256), 8192)), dim3(256), 0, st, y, yst, dy, gst, act, n / 4);
+    ACL_CHECK_LAUNCH("act_bwd_st_kernel");
+    return ACLGAN_OK;
+}
+
+// ---- storage conversion (fp32 <-> bf16 / fp16), four elements per thread ----
+__global__ void cast_storage_kernel(const void* __restrict__ src, int sst, void* __restrict__ dst, int dst_st, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) st_st4(dst, i, st_ld4(src, i, sst), dst_st);
+}
+int cast_storage(const void* src, int src_st, void* dst, int dst_st, int64_t n, hipStream_t st) {
+    ACL_REQUIRE(n % 4 == 0, "cast_storage: n %% 4 != 0");
+    if (n == 0) return ACLGAN_OK;
+    hipLaunchKernelGGL(cast_storage_kernel, dim3((int)std::min<int64_t>(cdiv64(n / 4, 256), 8192)), dim3(256), 0, st, src, src_st, dst, dst_st, n / 4);
+    ACL_CHECK_LAUNCH("cast_storage_kernel");
     return ACLGAN_OK;
 }
 
@@ -290,32 +319,32 @@ int linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, c
 }
 
 // ---- global average pool ----
-__global__ void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C) {
+__global__ void gap_fwd_kernel(const void* __restrict__ x, int xst, float* __restrict__ y, int HW, int C) {
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     float s = 0.f;
     if (c < C)
-        for (int p = pl; p < HW; p += 4) s += x[((size_t)b * HW + p) * C + c];
+        for (int p = pl; p < HW; p += 4) s += st_ld1(x, ((int64_t)b * HW + p) * C + c, xst);
     __shared__ float red[4][64];
     red[pl][threadIdx.x & 63] = s;
     __syncthreads();
     if (pl == 0 && c < C) y[(size_t)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW;
 }
-__global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int C, int acc, int64_t n) {
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, void* __restrict__ dx, int xst, int HW, int C, int acc, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int64_t b = i / ((int64_t)HW * C);
         const float v = dy[b * C + c] / (float)HW;
-        dx[i] = acc ? dx[i] + v : v;
+        st_st1(dx, i, acc ? st_ld1(dx, i, xst) + v : v, xst);
     }
 }
-int gap_fwd(int B, int HW, int C, const float* x, float* y, hipStream_t st) {
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, st, x, y, HW, C);
+int gap_fwd(int B, int HW, int C, const void* x, float* y, hipStream_t st, int xst) {
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, st, x, xst, y, HW, C);
     ACL_CHECK_LAUNCH("gap_fwd_kernel");
     return ACLGAN_OK;
 }
-int gap_bwd(int B, int HW, int C, const float* dy, float* dx, int accumulate, hipStream_t st) {
+int gap_bwd(int B, int HW, int C, const float* dy, void* dx, int accumulate, hipStream_t st, int xst) {
     const int64_t n = (int64_t)B * HW * C;
-    hipLaunchKernelGGL(gap_bwd_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, dy, dx, HW, C, accumulate, n);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, dy, dx, xst, HW, C, accumulate, n);
     ACL_CHECK_LAUNCH("gap_bwd_kernel");
     return ACLGAN_OK;
 }

@@ -190,12 +190,21 @@ def dominant_kernel_probe(L, dtype, reps=20):
                "pipeline_traffic": 469.0e6 if wino else 240.6e6, "pipeline_algorithmic_bytes": 69.5e6}
         return out
     code = L.DTYPE[dtype]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
     w16 = torch.empty(w.numel(), dtype=torch.int16, device="cuda")
     L.check(L.lib.aclgan_pack_weights16(L.ptr(w), L.ptr(w16), None, Cc, 9, Cc, code, st))
-    ms = timed(lambda: L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), code, L.ptr(x), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), None, st)))
-    return {"name": "conv_fwd16_kernel<%s> 8x64x64x256->256 3x3 (ResBlock conv, fp32 activations in HBM)" % dtype, "ms": round(ms, 4),
-            "flop_per_launch": flop_direct, "achieved": round(flop_direct / ms / 1e9, 2), "unit": "TFLOP/s",
-            "frac": round(flop_direct / ms / 1e9 / PEAK[dtype], 4), "traffic": None, "algorithmic_bytes": 69.5e6 - w.numel() * 2}
+    if L.lib.aclgan_conv16s_ok(C.byref(d), 0) and os.environ.get("ACLGAN_ACT16", "1") not in ("0",):
+        # the ResBlock convolution as the 16-bit step runs it: activations stored in the compute dtype, operand tiles global -> LDS
+        x16 = x.to(tdt); y16 = torch.empty(B, H, H, Cc, device="cuda", dtype=tdt)
+        ms = timed(lambda: L.check(L.lib.aclgan_conv2d_fwd16s(C.byref(d), code, L.ptr(x16), L.ptr(w16), L.ptr(b), L.ptr(y16), code, st)))
+        name = "conv_fwd16s_kernel<%s,128> 8x64x64x256->256 3x3 (ResBlock conv; %s activations in HBM, LDS-DMA operand tiles)" % (dtype, dtype)
+        alg = 2.0 * (x.numel() + y.numel() + w.numel())
+    else:
+        ms = timed(lambda: L.check(L.lib.aclgan_conv2d_fwd16(C.byref(d), code, L.ptr(x), L.ptr(w), L.ptr(w16), L.ptr(b), L.ptr(y), None, st)))
+        name = "conv_fwd16_kernel<%s> 8x64x64x256->256 3x3 (ResBlock conv, fp32 activations in HBM)" % dtype
+        alg = 4.0 * (x.numel() + y.numel()) + 2.0 * w.numel()
+    return {"name": name, "ms": round(ms, 4), "flop_per_launch": flop_direct, "achieved": round(flop_direct / ms / 1e9, 2), "unit": "TFLOP/s",
+            "frac": round(flop_direct / ms / 1e9 / PEAK[dtype], 4), "traffic": None, "algorithmic_bytes": alg}
 
 
 def spawn_ranks(args):

@@ -269,6 +269,33 @@ int aclgan_conv2d_dgrad16(const aclgan_conv_desc* d, int dtype, const float* dy,
                           float* dx, int accumulate, void* scratch, void* stream);
 int aclgan_conv2d_wgrad16(const aclgan_conv_desc* d, int dtype, const float* x, const float* dy, float* dw,
                           float* db, void* scratch, void* stream);
+
+/* ---- round 3: 16-bit ACTIVATION / GRADIENT STORAGE ("bf16 activations / MFMA, fp32 master") ----
+ * Under a 16-bit compute dtype the step keeps the activations and activation gradients of its wide layers (C % 64 == 0) in HBM in
+ * that dtype: the operand of networks.py:366's convolution is the same rounded value whether its producer or the conv loader
+ * rounds it, but the bytes halve and the operand tiles can go global -> LDS directly (csrc/conv_glds16.hip).  Storage codes:
+ * 0 = fp32, ACLGAN_DTYPE_BF16, ACLGAN_DTYPE_FP16.  Statistics, losses, master weights, weight gradients, Adam: fp32 as before. */
+/* which: 0 forward, 1 dgrad.  1 = the LDS-DMA kernels take this shape (no upsample, Cin and Cout multiples of 64, forward: grid that
+ * fills the chip without split-K) */
+int aclgan_conv16s_ok(const aclgan_conv_desc* d, int which);
+/* forward on 16-bit x (NHWC) and the OHWI weight pack: y (storage y_storage) = act(conv(x16) + bias) */
+int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, const void* w16, const float* bias, void* y, int y_storage, void* stream);
+/* dgrad on 16-bit dy and the transposed weight pack: dx (storage dx_storage) (+)= ...; ONE launch over the padded grid into `scratch`
+ * + an ordered fold of the reflection: no atomics, bit-reproducible */
+size_t aclgan_conv2d_dgrad16s_scratch_bytes(const aclgan_conv_desc* d);
+int aclgan_conv2d_dgrad16s(const aclgan_conv_desc* d, int dtype, const void* dy16, const void* w16t, void* dx, int dx_storage, int accumulate,
+                           void* scratch, void* stream);
+/* aclgan_conv2d_wgrad16 with either operand stored in the 16-bit dtype */
+int aclgan_conv2d_wgrad16_st(const aclgan_conv_desc* d, int dtype, const void* x, int x_storage, const void* dy, int dy_storage, float* dw, float* db,
+                             void* scratch, void* stream);
+/* elementwise storage conversion, n % 4 == 0 */
+int aclgan_cast_storage(const void* src, int src_storage, void* dst, int dst_storage, int64_t n, void* stream);
+/* aclgan_norm_fwd / aclgan_norm_bwd on tensors of any storage: storage = {x, y, residual} / {x, y, dy, dx, dres} */
+int aclgan_norm_fwd_st(int kind, int act, int B, int HW, int C, const void* x, const float* w, const float* b, int w_stride, const void* residual,
+                       void* y, float* mean, float* rstd, void* scratch, const int* storage, void* stream);
+int aclgan_norm_bwd_st(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy, const float* w, int w_stride,
+                       const float* mean, const float* rstd, void* dx, float* dw, float* db, void* dres, int dres_accumulate, void* scratch,
+                       const int* storage, void* stream);
 size_t aclgan_conv2d_fwd16_scratch_bytes(const aclgan_conv_desc* d);
 size_t aclgan_conv2d_dgrad16_scratch_bytes(const aclgan_conv_desc* d);
 size_t aclgan_conv2d_wgrad16_scratch_bytes(const aclgan_conv_desc* d);

@@ -234,25 +234,38 @@ def layer_norm_munit(x, gamma, beta):
 # products accumulate in (at least) fp32, everything else stays fp32.  The sub-pixel path of the
 # "Upsample(2) + 5x5" layers rounds the MERGED 3x3 phase filters (forward / dgrad, interior pixels only).
 # --------------------------------------------------------------------------------------
+# Round 3 -- 16-bit STORAGE: under a 16-bit compute dtype the build also keeps the activations and activation gradients of its wide
+# layers in HBM in that dtype (acl-gan_amd/csrc/engine.hip::conv_block):
+#   * the output of every Conv2dBlock with Cout % 64 == 0 is stored rounded (after norm / activation / residual add) -- except the one
+#     that feeds the 7x7 image-side output layer and the last layer of every discriminator scale (their consumers are fp32 kernels);
+#   * the conv output in front of a normalisation layer is stored rounded when the layer runs on the 16-bit-storage kernels (no
+#     upsample, Cin and Cout multiples of 64); statistics are then those of the stored values;
+#   * a gradient is rounded (at the loss scale it carries) where it is stored: the gradient w.r.t. a 16-bit activation -- unless a
+#     sub-pixel layer consumes it (those input-gradient kernels write fp32) -- and the gradient w.r.t. a 16-bit-stored conv output.
+# For a convolution operand none of this changes a value (the conv loaders rounded the same fp32 numbers before); what changes is
+# what the residual adds, the normalisation layers, the global average pool and the backward of norm / activation read.
 _QDT = None   # torch.bfloat16 / torch.float16 while emulating, else None (= the plain fp32 oracle)
 _QSCALE = 1.0  # fp16 loss scale S: every gradient that enters a 16-bit GEMM is S*dy (the build seeds the backward with S)
+_QSTORE = True  # emulate the 16-bit storage as well (compute_dtype(..., storage=False): the round-2 contract, fp32 storage)
+_QCO16 = True   # ... including the conv outputs in front of normalisation layers (the build's ACLGAN_CO16 switch)
 
 
 class compute_dtype:
     """with compute_dtype("bf16"): ... / with compute_dtype("fp16", loss_scale=65536.0): ...
     conv_block emulates the 16-bit MFMA contract inside the block (gradients come out UNscaled)."""
 
-    def __init__(self, name, loss_scale=1.0):
+    def __init__(self, name, loss_scale=1.0, storage=True):
         self.dt = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[name]
         self.scale = float(loss_scale)
+        self.storage = bool(storage)
 
     def __enter__(self):
-        global _QDT, _QSCALE
-        self.prev, _QDT, _QSCALE = (_QDT, _QSCALE), self.dt, self.scale
+        global _QDT, _QSCALE, _QSTORE
+        self.prev, _QDT, _QSCALE, _QSTORE = (_QDT, _QSCALE, _QSTORE), self.dt, self.scale, self.storage
 
     def __exit__(self, *a):
-        global _QDT, _QSCALE
-        _QDT, _QSCALE = self.prev
+        global _QDT, _QSCALE, _QSTORE
+        _QDT, _QSCALE, _QSTORE = self.prev
 
 
 def _q(t):
@@ -262,6 +275,19 @@ def _q(t):
 def _qg(dy):
     """a gradient operand: rounded at the loss scale it carries in the build"""
     return _q(dy * _QSCALE) / _QSCALE
+
+
+class _StoreQ(torch.autograd.Function):
+    """a tensor that lives in HBM in the 16-bit dtype: rounded on the way in; its gradient rounded likewise (g16) or kept fp32"""
+
+    @staticmethod
+    def forward(ctx, x, g16):
+        ctx.g16 = g16
+        return _q(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (_qg(dy) if ctx.g16 else dy), None
 
 
 def _plain_conv(x, w, stride, pad, upsample):
@@ -342,21 +368,40 @@ class _ConvQ(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
-def conv_block(x, w, b, stride, pad, act="none", norm="none", norm_args=None, upsample=False):
+def _store(y, g16=True):
+    """16-bit storage emulation of an activation (no-op outside compute_dtype(..., storage=True) and for narrow tensors)"""
+    if _QDT is None or not _QSTORE or y.shape[1] % 64 != 0:
+        return y
+    return _StoreQ.apply(y, g16)
+
+
+def conv_block(x, w, b, stride, pad, act="none", norm="none", norm_args=None, upsample=False, out16=True, g16=True, residual_follows=False):
     """Conv2dBlock.forward (networks.py:365-371): reflect pad -> conv(bias) -> norm -> act.
     ``upsample`` restates the nn.Upsample(scale_factor=2) (nearest) that precedes the two
-    5x5 decoder convs (networks.py:256)."""
+    5x5 decoder convs (networks.py:256).
+    out16 / g16 / residual_follows only matter under compute_dtype(..., storage=True) (see _QSTORE above): out16 = the block's output
+    is stored in the 16-bit dtype (when wide); g16 = so is its gradient; residual_follows = the caller adds the ResBlock residual
+    first and stores the sum itself (the build fuses the add into the normalisation kernel, one rounding)."""
     co, ci = w.shape[0], w.shape[1]
+    store = _QDT is not None and _QSTORE
+    s_bwd = ci % 64 == 0 and co % 64 == 0 and not upsample       # the layer's backward runs on the 16-bit-storage kernels
     if _QDT is not None and ci % 32 == 0 and co % 32 == 0:
         ok64 = ci % 64 == 0 and co % 64 == 0
         y = _ConvQ.apply(x, w, b, stride, pad, upsample, True, True, ok64)
-        return _norm_act(y, act, norm, norm_args)
-    if upsample:
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
-    if pad > 0:
-        x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
-    y = F.conv2d(x, w, b, stride=stride)
-    return _norm_act(y, act, norm, norm_args)
+        if store and s_bwd and norm != "none" and _QCO16:
+            y = _StoreQ.apply(y, True)                   # conv output in front of a normalisation layer, stored by the 16-bit-storage kernels
+        y = _norm_act(y, act, norm, norm_args)
+    else:
+        if upsample:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        if pad > 0:
+            x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
+        y = _norm_act(F.conv2d(x, w, b, stride=stride), act, norm, norm_args)
+    if store and out16 and not residual_follows:
+        # a block without normalisation hands its gradient straight to its own backward kernels: 16-bit only when those are the
+        # 16-bit-storage kernels
+        y = _store(y, g16 and (norm != "none" or s_bwd))
+    return y
 
 
 def _norm_act(y, act, norm, norm_args):
@@ -394,8 +439,8 @@ def content_encode(P: Params, x, g: dict):
     for r in range(nr):
         pre = "enc_content.model.%d.model.%d.model." % (nd + 1, r)
         t = conv_block(h, P[pre + "0.conv.weight"], P[pre + "0.conv.bias"], 1, 1, "relu", "in")
-        t = conv_block(t, P[pre + "1.conv.weight"], P[pre + "1.conv.bias"], 1, 1, "none", "in")
-        h = t + h  # networks.py:309
+        t = conv_block(t, P[pre + "1.conv.weight"], P[pre + "1.conv.bias"], 1, 1, "none", "in", residual_follows=True)
+        h = _store(t + h)  # networks.py:309
     return h
 
 
@@ -423,13 +468,14 @@ def decode(P: Params, content, style, g: dict):
         b1, w1 = ap[:, 2 * C * j: 2 * C * j + C], ap[:, 2 * C * j + C: 2 * C * (j + 1)]
         j += 1
         t = conv_block(h, P[pre + "0.conv.weight"], P[pre + "0.conv.bias"], 1, 1, "relu", "adain", (w0, b0))
-        t = conv_block(t, P[pre + "1.conv.weight"], P[pre + "1.conv.bias"], 1, 1, "none", "adain", (w1, b1))
-        h = t + h
+        t = conv_block(t, P[pre + "1.conv.weight"], P[pre + "1.conv.bias"], 1, 1, "none", "adain", (w1, b1), residual_follows=True)
+        h = _store(t + h, g16=(r + 1 < nr))      # the last block feeds a sub-pixel layer, whose input-gradient kernels write fp32
     idx = 2
     for i in range(nd):
         pre = "dec.model.%d." % idx
+        # (the last of these feeds the fp32 7x7 output layer: stored fp32; the others feed the next sub-pixel layer: fp32 gradient)
         h = conv_block(h, P[pre + "conv.weight"], P[pre + "conv.bias"], 1, 2, "relu", "ln",
-                       (P[pre + "norm.gamma"], P[pre + "norm.beta"]), upsample=True)
+                       (P[pre + "norm.gamma"], P[pre + "norm.beta"]), upsample=True, out16=(i + 1 < nd), g16=False)
         idx += 2
     pre = "dec.model.%d." % (idx - 1)
     return conv_block(h, P[pre + "conv.weight"], P[pre + "conv.bias"], 1, 3, "tanh")
@@ -456,7 +502,7 @@ def dis_forward(P: Params, x, dcfg: dict) -> List[torch.Tensor]:
     for s in range(dcfg["num_scales"]):
         h = x
         for i in range(nl):
-            h = conv_block(h, P["cnns.%d.%d.conv.weight" % (s, i)], P["cnns.%d.%d.conv.bias" % (s, i)], 2, 1, "lrelu")
+            h = conv_block(h, P["cnns.%d.%d.conv.weight" % (s, i)], P["cnns.%d.%d.conv.bias" % (s, i)], 2, 1, "lrelu", out16=(i + 1 < nl))
         outs.append(F.conv2d(h, P["cnns.%d.%d.weight" % (s, nl)], P["cnns.%d.%d.bias" % (s, nl)]))
         x = avgpool3s2(x)
     return outs

@@ -185,14 +185,18 @@ def _shard_trainers(cfg, nets, n):
     return trs
 
 
-@pytest.mark.parametrize("global_focus", [True, False])
-def test_shard_equivalence_on_one_gpu(global_focus):
+def test_shard_equivalence_on_one_gpu():
     """SURVEY.md 8e's correctness statement for the data-parallel step, checked without a second GPU: one trainer on a batch of 4
     versus two trainers on its halves whose gradient buffers are averaged by hand (what the RCCL AVG all-reduce does).
-    dis_update is linear in the batch: equal.  gen_update: equal when the focus 'size' loss sees the GLOBAL mask sums
-    (ddp_global_focus: the forward sync point is fed the sum of both shards' totals, exactly what the 6-float all-reduce produces);
-    without it (standard DDP semantics) everything the size loss reaches through the masks differs and nothing else does -- the
-    hyper-parameters are chosen so that the size term is ACTIVE (relu(sum(m - upper)) > 0), otherwise the test would be vacuous."""
+      * dis_update is linear in the batch: the averaged shard gradients equal the full-batch gradients.
+      * gen_update with ddp_global_focus semantics (the forward sync point is fed the SUM of both shards' six mask totals -- what the
+        6-float all-reduce produces): equal again, and every rank reports the global-batch focus losses.
+      * gen_update without it (standard DDP semantics: each rank squares ITS OWN mask sum): visibly different.  To make that
+        difference visible rather than a rounding-level effect the fixture picks focus_upper BETWEEN the two shards' mean mask
+        values of f_A, so that the size term relu(sum(m - upper))^2 of that mask is active on the whole batch and on one shard but
+        switched off by the relu on the other, and raises focus_delta so that the term carries weight in the total gradient.
+    "Equal" = to the level at which two HIP runs at different batch sizes agree at all: the forward of a sample is not bit-identical
+    between B=2 and B=4 (different split-K plans), so a few ReLU masks flip (measured 3.5e-4 relative L2 over the whole buffer)."""
     import ctypes as C
     import aclgan_amd  # noqa: F401
     from aclgan_amd import _lib as L
@@ -200,80 +204,89 @@ def test_shard_equivalence_on_one_gpu(global_focus):
     cfg = O.default_config()
     cfg["gen"].update(dim=16, mlp_dim=32, n_res=2); cfg["dis"].update(dim=16); cfg["display_size"] = 1
     cfg["focus_epsilon"] = 0.5        # smooth digit term
-    cfg["focus_upper"] = 0.45         # masks sit around 0.5 at init: sum(m - 0.45) > 0 -> the size loss and its gradient are non-zero
     nets = O.test_nets(cfg, 3)
     g = torch.Generator().manual_seed(43)
     x_a = torch.rand(4, 3, 128, 128, generator=g) * 2 - 1
     x_b = torch.rand(4, 3, 128, 128, generator=g) * 2 - 1
+    x_a[2:] *= 0.25                   # the two shards see differently distributed images -> different mean mask values
     z = [torch.randn(4, 8, 1, 1, generator=g) for _ in range(6)]
-    full, s0, s1 = _shard_trainers(cfg, nets, 3)
-    shards = (s0, s1)
+    full, s0, s1, t0, t1 = _shard_trainers(cfg, nets, 5)
 
     def sl(t, r):
         return t[2 * r: 2 * r + 2]
 
     # ---- dis_update: averaged shard gradients == full-batch gradients ----
     full.dis_update(x_a, x_b, cfg, z=z[:3])
-    for r, tr in enumerate(shards):
+    for r, tr in enumerate((s0, s1)):
         tr.dis_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[:3]])
     torch.cuda.synchronize()
     avg = 0.5 * (s0._grad[1] + s1._grad[1])
-    err = ((avg - full._grad[1]).double().norm() / full._grad[1].double().norm()).item()
-    print("shard equivalence, dis_update: relative L2 of the averaged gradient buffer %.2e" % err)
-    assert err <= 1e-4, err
+    err_d = ((avg - full._grad[1]).double().norm() / full._grad[1].double().norm()).item()
+    print("shard equivalence, dis_update: relative L2 of the averaged gradient buffer %.2e" % err_d)
+    assert err_d <= 1e-4, err_d
     assert abs(0.5 * (float(s0.loss_dis_total) + float(s1.loss_dis_total)) - float(full.loss_dis_total)) <= 1e-5 * abs(float(full.loss_dis_total))
+    # (the generators were not touched by dis_update: all five trainers still hold the same generator weights)
 
-    # ---- gen_update ----
+    # ---- the fixture: focus_upper between the shards' mean values of mask A ----
+    c2, _ = full.gen_BA.encode(x_a)
+    fA = full.gen_BA.decode(c2, cfg["alpha"] * z[4].cuda())[:, 3:]
+    m = ((fA + 1) * 0.5).double()
+    mean0, mean1 = m[:2].mean().item(), m[2:].mean().item()
+    gap = abs(mean0 - mean1)
+    assert gap > 1e-5, (mean0, mean1)
+    cfg = dict(cfg)
+    cfg["focus_upper"] = 0.5 * (mean0 + mean1) - 0.25 * gap      # global sum(m - upper) = +0.5 gap x pixels; one shard +, the other -
+    cfg["focus_delta"] = 1.0 / max(gap, 1e-4)                     # weight of the size term ~ independent of how small the gap is
+    cfg["focus_lower"] = 0.0                                      # masks are >= 0: the lower-bound half relu(sum(lower - m))^2 of the size loss stays off
     full.gen_update(x_a, x_b, cfg, z=z[3:])
-    assert float(full.loss_gen_focus_A_size) > 0 or float(full.loss_gen_focus_B_size) > 0, "fixture: the size term must be active"
-    cbs = []
-    if global_focus:
-        # pass 1: capture each shard's 6 local totals at its forward sync point; pass 2: feed every shard the SUM (= all-reduce SUM)
-        local = {}
-        mode = {"write": None}
+    assert float(full.loss_gen_focus_A_size) > 0, "fixture: the size term of mask A must be active on the whole batch"
 
-        def make(rank, tr):
-            def on_sync(user, ptr, n):
-                off = int(ptr) - tr._ws.data_ptr()
-                t = tr._ws[off: off + 4 * n].view(torch.float32)
-                if mode["write"] is None:
-                    local[rank] = t.clone()
-                else:
-                    t.copy_(mode["write"])
-            return L.SYNC_FN(on_sync)
-        for r, tr in enumerate(shards):
-            cb = make(r, tr); cbs.append(cb)
-            L.check(L.lib.aclgan_set_forward_sync(tr._ctx, cb, None, 2), "set_forward_sync")
-            p0 = tr._param[0].clone(); m0 = tr._m[0].clone(); v0 = tr._v[0].clone(); st0 = tr._opt[0]["steps"]
-            tr.gen_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[3:]])
-            torch.cuda.synchronize()
-            tr._param[0].copy_(p0); tr._m[0].copy_(m0); tr._v[0].copy_(v0); tr._opt[0]["steps"] = st0      # undo pass 1's Adam step
-        mode["write"] = local[0] + local[1]
-    for r, tr in enumerate(shards):
+    # ---- with the global sums: pass 1 captures each shard's six local totals, pass 2 feeds every shard their SUM ----
+    local, mode, cbs = {}, {"write": None}, []
+
+    def make(rank, tr):
+        def on_sync(user, ptr, n):
+            off = int(ptr) - tr._ws.data_ptr()
+            t = tr._ws[off: off + 4 * n].view(torch.float32)
+            if mode["write"] is None:
+                local[rank] = t.clone()
+            else:
+                t.copy_(mode["write"])
+        return L.SYNC_FN(on_sync)
+    for r, tr in enumerate((s0, s1)):
+        cb = make(r, tr); cbs.append(cb)
+        L.check(L.lib.aclgan_set_forward_sync(tr._ctx, cb, None, 2), "set_forward_sync")
+        p0 = tr._param[0].clone(); m0 = tr._m[0].clone(); v0 = tr._v[0].clone(); st0 = tr._opt[0]["steps"]
+        tr.gen_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[3:]])
+        torch.cuda.synchronize()
+        tr._param[0].copy_(p0); tr._m[0].copy_(m0); tr._v[0].copy_(v0); tr._opt[0]["steps"] = st0      # undo pass 1's Adam step
+    mode["write"] = local[0] + local[1]
+    for r, tr in enumerate((s0, s1)):
         tr.gen_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[3:]])
     torch.cuda.synchronize()
-    for tr in shards:
+    for tr in (s0, s1):
         L.lib.aclgan_set_forward_sync(tr._ctx, C.cast(None, L.SYNC_FN), None, 1)
-    avg = 0.5 * (s0._grad[0] + s1._grad[0])
     ref = full._grad[0]
-    err = ((avg - ref).double().norm() / ref.double().norm()).item()
-    print("shard equivalence, gen_update (global focus sums: %s): relative L2 of the averaged gradient buffer %.2e" % (global_focus, err))
-    if global_focus:
-        assert err <= 1e-4, err
-        for n in ("loss_gen_focus_A_size", "loss_gen_focus_B_size", "loss_gen_focus_A2_size", "loss_gen_total"):      # global-batch values on every rank
-            assert abs(float(getattr(s0, n)) - float(getattr(full, n))) <= 1e-4 * max(1e-6, abs(float(getattr(full, n)))), n
-    else:
-        # per-rank size loss (standard DDP semantics): delta * relu(T_r)^2 / (H W b 3) on each half instead of delta * relu(T_0 + T_1)^2 /
-        # (H W 2b 3) on the whole batch.  With T_0 ~ T_1 the full-batch VALUE is ~2x the mean of the shard values while the GRADIENTS
-        # nearly coincide (2 T / 2b vs 2 T_r / b): the difference is the imbalance T_r - T / 2 between the shards' masks
-        fs, ss = float(full.loss_gen_focus_A_size), 0.5 * (float(s0.loss_gen_focus_A_size) + float(s1.loss_gen_focus_A_size))
-        assert 1.5 * ss < fs < 2.5 * ss, (fs, ss)
-        assert err <= 5e-2, err
-        # everything that is linear in the batch still agrees: the reported batch-mean losses average exactly
-        for n in ("loss_gen_adv_A", "loss_gen_adv_B", "loss_gen_adv_2", "loss_idt_A", "loss_idt_B", "loss_gen_focus_A_digit"):
-            want = float(getattr(full, n))
-            got = 0.5 * (float(getattr(s0, n)) + float(getattr(s1, n)))
-            assert abs(got - want) <= 2e-5 * max(1e-6, abs(want)), (n, got, want)
+    err_g = ((0.5 * (s0._grad[0] + s1._grad[0]) - ref).double().norm() / ref.double().norm()).item()
+    # ---- without: standard DDP semantics ----
+    for r, tr in enumerate((t0, t1)):
+        tr.gen_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[3:]])
+    torch.cuda.synchronize()
+    err_l = ((0.5 * (t0._grad[0] + t1._grad[0]) - ref).double().norm() / ref.double().norm()).item()
+    print("shard equivalence, gen_update: relative L2 of the averaged gradient buffer: %.2e with the global focus sums, %.2e with per-rank sums "
+          "(mask A means %.6f / %.6f, focus_upper %.6f)" % (err_g, err_l, mean0, mean1, cfg["focus_upper"]))
+    assert err_g <= 2e-3, err_g
+    assert err_l >= 10 * err_g, (err_l, err_g)
+    for n in ("loss_gen_focus_A_size", "loss_gen_focus_B_size", "loss_gen_focus_A2_size", "loss_gen_total"):      # global-batch values on every rank
+        for tr in (s0, s1):
+            assert abs(float(getattr(tr, n)) - float(getattr(full, n))) <= 2e-3 * max(1e-6, abs(float(getattr(full, n)))), (n, float(getattr(tr, n)), float(getattr(full, n)))
+    # per-rank semantics: one shard's relu switched the term off
+    assert min(float(t0.loss_gen_focus_A_size), float(t1.loss_gen_focus_A_size)) == 0.0
+    # everything that is linear in the batch agrees in both modes: the reported batch-mean losses average exactly
+    for n in ("loss_gen_adv_A", "loss_gen_adv_B", "loss_gen_adv_2", "loss_idt_A", "loss_idt_B"):
+        want = float(getattr(full, n))
+        got = 0.5 * (float(getattr(t0, n)) + float(getattr(t1, n)))
+        assert abs(got - want) <= 2e-5 * max(1e-6, abs(want)), (n, got, want)
 
 
 def test_train_py_two_ranks_share_one_gpu(tmp_path):

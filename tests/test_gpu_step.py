@@ -115,7 +115,7 @@ def test_forward_matches_reference(T, fix):
 
 # per-tensor relative L2 of the HIP gradients against the fp32 oracle at 64x64, B <= 2 (measured worst, final round-3 build, recorded
 # in profiles/r03_gpu_tests.log): one ReLU mask flip moves an upstream tensor by ~1 / sqrt(#elements of the layer)
-ETOL_SMOOTH, ETOL_DEFAULT = 6e-2, 1.5e-1
+ETOL_SMOOTH, ETOL_DEFAULT = 3e-2, 3e-2      # measured worst 9.6e-3 (reduced width, smooth) / 4.7e-3 (full width, default epsilon)
 
 
 def _grads_by_name(tr, nets):
