@@ -542,6 +542,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, WgPa
     u32x4* mytile = isA ? As : Bs;
     const int tstride = (isA ? BM : BN) * LDQ;
     f32x4 rr[8];
+    uint2 rh[8];                               // 16-bit storage: 4 channels x 16 bit per pixel
     float zm[8];
     const bool do_bias = p.db != nullptr && (tile % p.tiles_n) == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -575,12 +576,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, WgPa
                         rr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
                         zm[j] = cb + pb + j < ce ? 1.f : 0.f;     // pixels past the sub-chunk contribute nothing (masking both operands is harmless)
                     }
-                } else {      // 16-bit storage: 4 channels = 8 bytes per pixel, kept in the first two lanes of rr[j]
+                } else {      // 16-bit storage: 4 channels = 8 bytes per pixel
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int2 pi = pinfo[pb + j];
-                        const st_u32x2 h = *reinterpret_cast<const st_u32x2*>(reinterpret_cast<const u16*>(src) + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
-                        rr[j][0] = __builtin_bit_cast(float, h[0]); rr[j][1] = __builtin_bit_cast(float, h[1]);
+                        const unsigned int* hp = reinterpret_cast<const unsigned int*>(reinterpret_cast<const u16*>(src) + (size_t)(isA ? pi.y : pi.x) * cstride + chan);
+                        rh[j] = *reinterpret_cast<const uint2*>(hp);
                         zm[j] = cb + pb + j < ce ? 1.f : 0.f;
                     }
                 }
@@ -606,8 +607,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_wgrad16_kernel(WgFP p, WgPa
                     unsigned int h[8][2];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        h[j][0] = zm[j] != 0.f ? __builtin_bit_cast(unsigned int, rr[j][0]) : 0u;
-                        h[j][1] = zm[j] != 0.f ? __builtin_bit_cast(unsigned int, rr[j][1]) : 0u;
+                        h[j][0] = zm[j] != 0.f ? rh[j].x : 0u;
+                        h[j][1] = zm[j] != 0.f ? rh[j].y : 0u;
                     }
                     if (do_bias && isA && real) {
 #pragma unroll

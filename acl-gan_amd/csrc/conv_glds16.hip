@@ -122,14 +122,17 @@ struct FwdSP {
     float2* stats;     // optional: per (128-row tile, channel) (mean, M2) of the stored outputs -- the normalisation layer's chunk partials
 };
 
-template <class T, int BN>
-__global__ void __launch_bounds__(256, 2) conv_fwd16s_kernel(FwdSP p) {
+// NBUF = 2: two LDS buffers, one barrier per k-tile, 2 workgroups per CU (the DMA of tile t+1 flies under tile t's MFMAs of the same
+// workgroup).  NBUF = 1: one buffer, two barriers per k-tile, half the LDS -> 4 workgroups per CU: the other three workgroups' MFMAs
+// cover a workgroup's DMA issue + flight (an LDS-DMA issue costs its wave ~100-180 cycles, eight per k-tile against 512 MFMA cycles).
+template <class T, int BN, int NBUF>
+__global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(FwdSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (device pass only: the host pass cannot instantiate a template body that declares __amdgpu_buffer_rsrc_t locals -- its launch stub would stay undefined)
 
     constexpr int BM = 128, TM = 2, TN = BN / 64, B_IT = BN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES) + BM * 4];
-    int* ro = reinterpret_cast<int*>(smem + 2 * (A_BYTES + B_BYTES));
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * (A_BYTES + B_BYTES) + BM * 4];
+    int* ro = reinterpret_cast<int*>(smem + NBUF * (A_BYTES + B_BYTES));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd16s_kernel(FwdSP p) {
             }
         }
         unsigned char* da = smem + buf * A_BYTES + (32 * wave) * ROWB;
-        unsigned char* db = smem + 2 * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
+        unsigned char* db = smem + NBUF * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
 #pragma unroll
         for (int n = 0; n < 4; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
 #pragma unroll
@@ -192,12 +195,21 @@ __global__ void __launch_bounds__(256, 2) conv_fwd16s_kernel(FwdSP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        __syncthreads();                           // (vmcnt(0) +) barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-        mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + 2 * A_BYTES + cur * B_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+    if (NBUF == 2) {
+        issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            __syncthreads();                       // (vmcnt(0) +) barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
+            if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+            mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            issue(kt, 0);
+            __syncthreads();                       // tile kt has landed
+            mma_tile<T, TM, TN>(smem + (wm * 64) * ROWB, smem + A_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+            __syncthreads();                       // every wave is done reading: the buffer may be refilled
+        }
     }
 
     const float* bias = p.bias;
@@ -212,8 +224,12 @@ int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
     const int BN = g.Co % 128 == 0 ? 128 : 64;
     p.tiles_n = g.Co / BN;
     p.nwg = cdiv(g.M, 128) * p.tiles_n;
-    if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128>), dim3(p.nwg), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 64>), dim3(p.nwg), dim3(256), 0, st, p);
+    static int nbuf = 0;
+    if (!nbuf) { const char* e = getenv("ACLGAN_GLDS_NBUF"); nbuf = (e && atoi(e) == 1) ? 1 : 2; }
+    if (BN == 128 && nbuf == 2) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128, 2>), dim3(p.nwg), dim3(256), 0, st, p);
+    else if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128, 1>), dim3(p.nwg), dim3(256), 0, st, p);
+    else if (nbuf == 2) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 64, 2>), dim3(p.nwg), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 64, 1>), dim3(p.nwg), dim3(256), 0, st, p);
     ACL_CHECK_LAUNCH("conv_fwd16s_kernel");
     return ACLGAN_OK;
 }

@@ -311,6 +311,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     ConvGeom g;
     CHK(make_geom(&d, &g));
     if (!W.w) { set_error("conv_block: parameters not bound"); return ACLGAN_EINVAL; }
+    Act* const gin = in;                          // the tensor this block's input gradient is delivered to
     const bool want_grad = train_w || in->need_grad || ns.dw != nullptr;
     const bool has_norm = ns.kind != ACLGAN_NORM_NONE;
     // 16-bit MFMA path (compute dtype bf16 / fp16): per operator, whenever the shape has a 16-bit kernel
@@ -320,7 +321,14 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     const bool a16 = h16 && c.act16();
     const bool s_bwd = a16 && f16 && d16 && w16 && conv16s_ok(g, 1);                 // backward on the 16-bit-storage kernels
     const bool s_fwd = a16 && f16 && conv16s_ok(g, 0) && in->dt != 0;                 // forward on the LDS-DMA kernel
-    if (in->dt != 0 && !f16) { set_error("conv_block: a 16-bit activation reached a layer without a 16-bit kernel (Cin %d, Cout %d, k %d)", g.Ci, g.Co, g.k); return ACLGAN_EINVAL; }
+    if (in->dt != 0 && !(f16 && (w16 || !train_w))) {
+        // a 16-bit activation reaches a layer whose forward or weight-gradient kernel only reads fp32 (odd widths of reduced test
+        // networks: Cout or Cin a multiple of 32 but not of 64): one fp32 copy serves both; the input gradient goes to the original
+        Act* in32 = c.new_act(in->B, in->H, in->W, in->C, false, 0);
+        NEED(in32->d);
+        RUN(cast_storage(in->d, in->dt, in32->d, 0, in->numel(), c.st));
+        in = in32;                                // data source of this block; gradients still go to the original (gin)
+    }
     const int out_st = (a16 && Co % 64 == 0 && out16) ? dt : 0;
     const int co_st = has_norm ? ((s_bwd && aclgan_ctx::co16_enabled()) ? dt : 0) : ((f16 || !out_st) ? out_st : 0);
     Act* co = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad, co_st);
@@ -342,7 +350,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     } else {
         out->gdt = s_bwd ? co_st : 0;         // (fp32 d with 16-bit-storage backward kernels: converted out of place in the backward)
     }
-    if (in->need_grad && !s_bwd) in->gdt = 0;   // this layer's input-gradient kernels write fp32
+    if (gin->need_grad && !s_bwd) gin->gdt = 0;   // this layer's input-gradient kernels write fp32
     // Winograd layers: the forward's input transform V = B^T x B is exactly what the weight gradient needs again -- keep it (persistent
     // until the tape has run: 75 MB per ResBlock convolution at 256x256 B=8, ~6 GB per update) instead of recomputing it
     // Bounded: the kept transforms of one update may take at most keepv_budget() bytes of the arena (default 64 GB of the 288 GB; 256x256
@@ -388,10 +396,10 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         aclgan_ctx& c = *cp;
         if (!out->gw) return ACLGAN_OK;   // no gradient reached this block
         // backward of norm / activation: x (or y), dy -> dx (+ dres); wgrad: x, dy -> dw, db; dgrad: dy, w -> dx
-        const double eg_out = out->gdt ? 2.0 : 4.0, eg_co = (has_norm ? co->gdt : (s_bwd ? dt : out->gdt)) ? 2.0 : 4.0, eg_in = in->gdt ? 2.0 : 4.0;
+        const double eg_out = out->gdt ? 2.0 : 4.0, eg_co = (has_norm ? co->gdt : (s_bwd ? dt : out->gdt)) ? 2.0 : 4.0, eg_in = gin->gdt ? 2.0 : 4.0;
         c.count((es_co + eg_out + eg_co) * (double)co->numel() + ((residual && residual->need_grad) ? (residual->gdt ? 2.0 : 4.0) * (double)co->numel() : 0.0));
         if (train_w) c.count(es_in * (double)in->numel() + eg_co * (double)co->numel() + 4.0 * ((double)Co * g.K + Co));
-        if (in->need_grad) c.count(eg_co * (double)co->numel() + es_w * (double)Co * g.K + eg_in * (double)in->numel());
+        if (gin->need_grad) c.count(eg_co * (double)co->numel() + es_w * (double)Co * g.K + eg_in * (double)in->numel());
         const size_t mark0 = c.top;
         const float* dyp = nullptr;       // gradient w.r.t. the conv output, as the dgrad / wgrad kernels read it
         int dy_st = 0;
@@ -429,21 +437,21 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             }
             c.top = mark;
         }
-        if (in->need_grad) {
+        if (gin->need_grad) {
             const size_t mark = c.top;
             if (s_bwd) {
                 if (!dy_st) { set_error("conv_block: 16-bit-storage dgrad on an fp32 gradient"); return ACLGAN_EINVAL; }
                 void* scr = c.alloc(conv_dgrad16s_scratch_bytes(g));
                 NEED(scr);
-                RUN(conv_dgrad16s(g, dt, dyp, W.w16t, in->g, in->gdt, in->gw ? 1 : 0, scr, c.st));
+                RUN(conv_dgrad16s(g, dt, dyp, W.w16t, gin->g, gin->gdt, gin->gw ? 1 : 0, scr, c.st));
             } else {
-                if (dy_st || in->gdt) { set_error("conv_block: fp32-output dgrad kernel on 16-bit gradients"); return ACLGAN_EINVAL; }
+                if (dy_st || gin->gdt) { set_error("conv_block: fp32-output dgrad kernel on 16-bit gradients"); return ACLGAN_EINVAL; }
                 void* scr = c.alloc(d16 ? conv_dgrad16_scratch_bytes(g) + 256 : conv_dgrad_scratch_bytes(g));
                 NEED(scr);
-                if (d16) RUN(conv_dgrad16(g, dt, dyp, W.w, W.w16t, in->g, in->gw ? 1 : 0, scr, c.st));
-                else RUN(conv_dgrad(g, dyp, W.w, in->g, scr, in->gw ? 1 : 0, c.st));
+                if (d16) RUN(conv_dgrad16(g, dt, dyp, W.w, W.w16t, gin->g, gin->gw ? 1 : 0, scr, c.st));
+                else RUN(conv_dgrad(g, dyp, W.w, gin->g, scr, gin->gw ? 1 : 0, c.st));
             }
-            mark_written(in);
+            mark_written(gin);
             c.top = mark;
         }
         c.top = mark0;

@@ -22,7 +22,7 @@ PY
 }
 echo "== stages: $STAGES" | tee $O/progress.log
 if has tests; then
-    (timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -s ${PYTEST_X--x} ${PYTEST_ARGS:-} 2>&1 | grep -vE "^\s*$" | cut -c 1-900) > $O/tests_full.log
+    (timeout ${TEST_TIMEOUT:-1500} python -m pytest ${PYTEST_PATHS:-tests} -m gpu -q -s ${PYTEST_X--x} ${PYTEST_ARGS:-} 2>&1 | grep -vE "^\s*$" | cut -c 1-900) > $O/tests_full.log
     grep -E "passed|failed|error" $O/tests_full.log | tail -3 | tee -a $O/progress.log
     grep -E "worst|passed|failed|rel errors|shard equivalence|chained|under the floor|Error|assert" $O/tests_full.log | cut -c 1-700 > $O/tests_summary.log
 fi

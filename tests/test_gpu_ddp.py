@@ -210,22 +210,22 @@ def test_shard_equivalence_on_one_gpu():
     x_b = torch.rand(4, 3, 128, 128, generator=g) * 2 - 1
     x_a[2:] *= 0.25                   # the two shards see differently distributed images -> different mean mask values
     z = [torch.randn(4, 8, 1, 1, generator=g) for _ in range(6)]
-    full, s0, s1, t0, t1 = _shard_trainers(cfg, nets, 5)
+    fulld, d0, d1, full, s0, s1, t0, t1 = _shard_trainers(cfg, nets, 8)      # (separate sets: an update also steps its optimizer)
 
     def sl(t, r):
         return t[2 * r: 2 * r + 2]
 
     # ---- dis_update: averaged shard gradients == full-batch gradients ----
-    full.dis_update(x_a, x_b, cfg, z=z[:3])
-    for r, tr in enumerate((s0, s1)):
+    fulld.dis_update(x_a, x_b, cfg, z=z[:3])
+    for r, tr in enumerate((d0, d1)):
         tr.dis_update(sl(x_a, r), sl(x_b, r), cfg, z=[sl(t, r) for t in z[:3]])
     torch.cuda.synchronize()
-    avg = 0.5 * (s0._grad[1] + s1._grad[1])
-    err_d = ((avg - full._grad[1]).double().norm() / full._grad[1].double().norm()).item()
+    avg = 0.5 * (d0._grad[1] + d1._grad[1])
+    err_d = ((avg - fulld._grad[1]).double().norm() / fulld._grad[1].double().norm()).item()
     print("shard equivalence, dis_update: relative L2 of the averaged gradient buffer %.2e" % err_d)
     assert err_d <= 1e-4, err_d
-    assert abs(0.5 * (float(s0.loss_dis_total) + float(s1.loss_dis_total)) - float(full.loss_dis_total)) <= 1e-5 * abs(float(full.loss_dis_total))
-    # (the generators were not touched by dis_update: all five trainers still hold the same generator weights)
+    assert abs(0.5 * (float(d0.loss_dis_total) + float(d1.loss_dis_total)) - float(fulld.loss_dis_total)) <= 1e-5 * abs(float(fulld.loss_dis_total))
+    del fulld, d0, d1
 
     # ---- the fixture: focus_upper between the shards' mean values of mask A ----
     c2, _ = full.gen_BA.encode(x_a)
