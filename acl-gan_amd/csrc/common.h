@@ -126,6 +126,10 @@ int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, 
 bool conv16s_ok(const ConvGeom& g, int which);
 int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st);
 size_t conv_dgrad16s_scratch_bytes(const ConvGeom& g);
+// weight gradient with BOTH operands in the 16-bit dtype (Cin, Cout multiples of 128): pixel-major LDS-DMA tiles + transposing LDS reads
+bool conv_wgrad16s_ok(const ConvGeom& g);
+size_t conv_wgrad16s_scratch_bytes(const ConvGeom& g);
+int conv_wgrad16s(const ConvGeom& g, int dtype, const void* x16, const void* dy16, float* dw, float* db, void* scratch, hipStream_t st);
 int conv_dgrad16s(const ConvGeom& g, int dtype, const void* dy16, const void* w16t, void* dx, int dxst, int accumulate, void* scratch, hipStream_t st);
 int cast_flat16(const float* src, void* dst, int64_t n, int dtype, hipStream_t st);
 int transpose_flat16(const float* base, void* base_t, const int64_t* offs, const int* co, const int* taps, const int* ci, int n, int dtype, hipStream_t st);

@@ -986,7 +986,7 @@ size_t conv_dgrad16_scratch_bytes(const ConvGeom& g) {
     if (deterministic()) return (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float);     // padded-grid gradient
     return up5_eligible(g) ? up5_w16_bytes(g) : 0;
 }
-size_t conv_wgrad16_scratch_bytes(const ConvGeom& g) { return wgrad16_ok(g) ? wgrad16_scratch(g) : 0; }
+size_t conv_wgrad16_scratch_bytes(const ConvGeom& g) { return wgrad16_ok(g) ? std::max(wgrad16_scratch(g), conv_wgrad16s_scratch_bytes(g)) : 0; }
 
 int conv_fwd16(const ConvGeom& g, int dtype, const float* x, const float* w, const void* w16, const float* bias, float* y, void* scratch, hipStream_t st,
                const void* x16, int y_storage) {
@@ -1008,6 +1008,7 @@ int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, 
                  int dy_storage) {
     if (!wgrad16_ok(g) || !dw) return ACLGAN_EUNSUPPORTED;
     const int xst = x_storage ? dtype : 0, dyst = dy_storage ? dtype : 0;
+    if (xst && dyst && scratch && conv_wgrad16s_ok(g)) return conv_wgrad16s(g, dtype, x, dy, dw, db, scratch, st);   // both operands 16-bit: the LDS-DMA kernel
     if (dtype == ACLGAN_DTYPE_BF16) return wgrad16_t<PBF16>(g, x, dy, dw, db, scratch, st, xst, dyst);
     if (dtype == ACLGAN_DTYPE_FP16) return wgrad16_t<PFP16>(g, x, dy, dw, db, scratch, st, xst, dyst);
     set_error("conv_wgrad16: dtype %d", dtype);

@@ -224,8 +224,12 @@ int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
     const int BN = g.Co % 128 == 0 ? 128 : 64;
     p.tiles_n = g.Co / BN;
     p.nwg = cdiv(g.M, 128) * p.tiles_n;
-    static int nbuf = 0;
-    if (!nbuf) { const char* e = getenv("ACLGAN_GLDS_NBUF"); nbuf = (e && atoi(e) == 1) ? 1 : 2; }
+    // buffers: one (4 workgroups per CU) once the grid fills those 1024 slots to 3/4, else two (2 per CU, DMA under the workgroup's own
+    // MFMAs).  Measured (profiles/r03_experiments.md): ResBlock shape B=8 (512 tiles) 53 us vs 58 us, B=32 (2048) 200 vs 173 us, first
+    // wide discriminator layer (768 tiles) 60 vs 46 us.  ACLGAN_GLDS_NBUF=1|2 forces one.
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ACLGAN_GLDS_NBUF"); force = e ? atoi(e) : 0; }
+    const int nbuf = force == 1 ? 1 : (force == 2 ? 2 : (p.nwg >= 768 ? 1 : 2));
     if (BN == 128 && nbuf == 2) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128, 2>), dim3(p.nwg), dim3(256), 0, st, p);
     else if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128, 1>), dim3(p.nwg), dim3(256), 0, st, p);
     else if (nbuf == 2) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 64, 2>), dim3(p.nwg), dim3(256), 0, st, p);
@@ -374,6 +378,193 @@ __global__ void __launch_bounds__(256) conv_fold_st_kernel(FoldSP f) {
     }
 }
 
+bool shape_ok(const ConvGeom& g);
+bool enabled();
+
+// ------------------------------------------------------------------------------------------
+// wgrad on 16-bit x and dy:  dW[co][tap][ci] = sum over pixels of dy[p][co] * x[src(p, tap)][ci]
+// The GEMM k axis is the PIXEL index, the slow axis of both NHWC operands, while an MFMA lane wants 8 consecutive k of one channel.
+// conv_fast16.hip transposes 8 pixels x 4 channels per staging thread in registers (v_perm) and writes channel-major LDS rows.  Here
+// both operand tiles stay pixel-major -- [64 pixels][128 channels], a pixel row is 256 contiguous bytes of HBM, so they are plain
+// LDS-DMA copies (x through a per-pixel gather table: reflection + filter tap) -- and the transposition happens in the LDS READ:
+// ds_read_b64_tr_b16 hands lane l channel (l & 15) of the 4 pixel rows its 16-lane group addresses (measured layout:
+// scripts/microbench/tr16_layout.hip), two of them make one 32x32x16 operand.  Bank conflicts of those reads (four pixel rows,
+// 256 B apart) are removed by XOR-ing the 16-byte chunk index with (pixel & 3) << 2 on the DMA source side and in the read address.
+// Pixel slices (blockIdx.z) store their 128 x 128 tiles, wgrad16s_finish_kernel adds them in order: no atomics, bit-reproducible.
+// The bias gradient (column sums of dy) is a separate ordered reduction (colsum16_kernel): no operand ever passes through registers.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgSP {
+    const u16* x16; const u16* dy16; float* part; float* part_b; float* dw; float* db;
+    int B, Hi, Wi, Ci, Ho, Wo, Co, k, s, p, P, Kn, chunk, tiles_n, nwg, splits, nsub, sub;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256, 2) conv_wgrad16s_kernel(WgSP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BK = 64, CH = 1024, PROW = 256;       // pixels per k-tile, pixels per gather-table refill, bytes per LDS pixel row (128 channels)
+    constexpr int T_BYTES = BK * PROW;                  // one operand tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * T_BYTES + (CH + BK) * 4];
+    int* pinfo = reinterpret_cast<int*>(smem + 4 * T_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_map(blockIdx.x, p.nwg);
+    const int m0 = (tile / p.tiles_n) * 128, n0 = (tile % p.tiles_n) * 128;
+    const int tap = n0 / p.Ci, ci0 = n0 - tap * p.Ci, ky = tap / p.k, kx = tap - ky * p.k;     // the whole N tile lies inside one filter tap
+    const int pbeg = blockIdx.z * p.chunk, pend = min(p.P, pbeg + p.chunk);
+    const int hw = p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy16, (long long)p.P * p.Co * 2);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x16, (long long)p.B * p.Hi * p.Wi * p.Ci * 2);
+    // DMA roles: instruction n (0..3) of wave w fills pixel rows 16 w + 4 n + (lane >> 4) of a tile, the lane its 16-byte chunk (lane & 15)
+    const int lp = lane >> 4;
+    const int swz = ((lane & 15) ^ (lp << 2)) * 16;     // source chunk of LDS position (lane & 15) in a row with pixel & 3 == lp
+    // fragment reads: lane l addresses, as member s = l & 15 of its 16-lane group, pixel row 8 (l >> 5) + (s >> 2) [+ 4], channels
+    // 16 ((l >> 4) & 1) + 4 (s & 3) .. + 3 of a 32-channel block, and receives channel (l & 31) of those 4 pixels
+    const int sl = lane & 15, sq = sl >> 2;
+    int fo_a[2], fo_b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ca = wm * 64 + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (sl & 3), cbn = wn * 64 + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+        fo_a[t] = (8 * (lane >> 5) + sq) * PROW + (((ca >> 3) ^ (sq << 2)) << 4) + (ca & 7) * 2;
+        fo_b[t] = (8 * (lane >> 5) + sq) * PROW + (((cbn >> 3) ^ (sq << 2)) << 4) + (cbn & 7) * 2;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int cb = pbeg; cb < pend; cb += CH) {
+        const int ce = min(pend, cb + CH);
+        for (int i = tid; i < CH + BK; i += 256) {       // source pixel of this tile's tap per sub-chunk pixel; -1 past the slice: reads zero
+            const int pix = cb + i;
+            int v = -1;
+            if (pix < ce) {
+                const int b = pix / hw, rem = pix - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                v = (b * p.Hi + refl(oy * p.s - p.p + ky, p.Hi)) * p.Wi + refl(ox * p.s - p.p + kx, p.Wi);
+            }
+            pinfo[i] = v;
+        }
+        __syncthreads();
+        const int nkt = (ce - cb + BK - 1) / BK;
+        auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+            unsigned char* da = smem + buf * 2 * T_BYTES + (16 * wave) * PROW;
+            unsigned char* db = da + T_BYTES;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int pl = kt * BK + 16 * wave + 4 * n + lp;
+                const int sp = pinfo[pl];
+                const int va = sp >= 0 ? ((cb + pl) * p.Co + m0) * 2 + swz : OOB;
+                const int vb = sp >= 0 ? (sp * p.Ci + ci0) * 2 + swz : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 4 * PROW), 16, va, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(db + n * 4 * PROW), 16, vb, 0, 0, 0);
+            }
+        };
+        issue(0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            __syncthreads();
+            if (kt + 1 < nkt) issue(kt + 1, cur ^ 1);
+            const unsigned char* ta = smem + cur * 2 * T_BYTES;
+            const unsigned char* tb = ta + T_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 fa[2], fb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ta + fo_a[t] + ks * 16 * PROW));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ta + fo_a[t] + ks * 16 * PROW + 4 * PROW));
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb + fo_b[t] + ks * 16 * PROW));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb + fo_b[t] + ks * 16 * PROW + 4 * PROW));
+                    const uint2 a0u = __builtin_bit_cast(uint2, a0), a1u = __builtin_bit_cast(uint2, a1);
+                    const uint2 b0u = __builtin_bit_cast(uint2, b0), b1u = __builtin_bit_cast(uint2, b1);
+                    fa[t] = (u32x4){a0u.x, a0u.y, a1u.x, a1u.y};
+                    fb[t] = (u32x4){b0u.x, b0u.y, b1u.x, b1u.y};
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+            }
+        }
+        __syncthreads();       // the gather table and both buffers are free for the next sub-chunk
+    }
+    // this slice's tile, natural [128 co][128 ci] order: 128-byte coalesced rows
+    float* pt = p.part + ((size_t)blockIdx.z * p.nwg + tile) * (128 * 128);
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pt[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + j * 32 + l31] = acc[i][j][r];
+#endif
+}
+
+// part_b[sub][c] = sum of dy16[p][c] over the sub-slice's pixels (64 channels x 16 pixel lanes per workgroup, ordered LDS combine)
+__global__ void __launch_bounds__(256) colsum16_kernel(WgSP p, int st) {
+    __shared__ st_f32x4 red[256];
+    const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int cblk = blockIdx.x, z = blockIdx.y;
+    const int p0 = z * p.sub, p1 = min(p.P, p0 + p.sub);
+    const int C4 = p.Co >> 2;
+    st_f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int px = p0 + pl; px < p1; px += 16) s += st_ld4(p.dy16, (int64_t)px * C4 + cblk * 16 + c4, st);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0) {
+        for (int i = 1; i < 16; ++i) s += red[i * 16 + c4];
+        *reinterpret_cast<st_f32x4*>(p.part_b + (size_t)z * p.Co + cblk * 64 + c4 * 4) = s;
+    }
+}
+
+// dw[m][n..n+3] += sum over slices (in order) of the partial tiles; db[m] += sum over the column-sum partials (in order)
+__global__ void __launch_bounds__(256) wgrad16s_finish_kernel(WgSP p) {
+    const int N4 = p.Kn >> 2;
+    const int64_t n = (int64_t)p.Co * N4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int n4 = (int)(i % N4), m = (int)(i / N4);
+        const int tile = (m >> 7) * p.tiles_n + ((n4 * 4) >> 7);
+        const float* pt = p.part + (size_t)tile * (128 * 128) + (size_t)(m & 127) * 128 + ((n4 * 4) & 127);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.splits; ++z) s += *reinterpret_cast<const f32x4*>(pt + (size_t)z * p.nwg * (128 * 128));
+        f32x4* o = reinterpret_cast<f32x4*>(p.dw + (size_t)m * p.Kn + n4 * 4);
+        *o += s;
+    }
+    if (p.db)
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.Co; m += gridDim.x * 256) {
+            float s = 0.f;
+            for (int z = 0; z < p.nsub; ++z) s += p.part_b[(size_t)z * p.Co + m];
+            p.db[m] += s;
+        }
+}
+
+struct WgSPlan { int tiles_n, nwg, splits, chunk, nsub, sub; size_t part_bytes, partb_bytes; };
+WgSPlan wgrad16s_plan(const ConvGeom& g) {
+    WgSPlan q;
+    q.tiles_n = g.K / 128;
+    q.nwg = (g.Co / 128) * q.tiles_n;
+    int splits = std::max(1, 512 / q.nwg);
+    splits = std::max(1, std::min(splits, cdiv(g.M, 512)));
+    q.chunk = cdiv(cdiv(g.M, splits), 64) * 64;
+    q.splits = cdiv(g.M, q.chunk);
+    q.nsub = std::max(1, std::min(256, g.M / 64));
+    q.sub = cdiv(g.M, q.nsub);
+    q.nsub = cdiv(g.M, q.sub);
+    q.part_bytes = ((size_t)q.splits * q.nwg * 128 * 128 * sizeof(float) + 255) & ~(size_t)255;
+    q.partb_bytes = ((size_t)q.nsub * g.Co * sizeof(float) + 255) & ~(size_t)255;
+    return q;
+}
+bool wgrad16s_shape_ok(const ConvGeom& g) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ACLGAN_NOWGRAD16S"); off = (e && atoi(e)) ? 1 : 0; }
+    return !off && enabled() && shape_ok(g) && g.Co % 128 == 0 && g.Ci % 128 == 0 && g.M >= 64;
+}
+
 bool shape_ok(const ConvGeom& g) {
     return fast_enabled() && g.up == 0 && g.Ci % 64 == 0 && g.Co % 64 == 0 && g.k >= 1 && g.p < g.Hi && g.p < g.Wi;
 }
@@ -437,6 +628,36 @@ int conv_dgrad16s(const ConvGeom& g, int dtype, const void* dy16, const void* w1
     f.total = (int64_t)g.B * g.Hi * g.Wi * (g.Ci / 4);
     hipLaunchKernelGGL(conv_fold_st_kernel, dim3((int)std::min<int64_t>(cdiv64(f.total, 256), 16384)), dim3(256), 0, st, f);
     ACL_CHECK_LAUNCH("conv_fold_st_kernel");
+    return ACLGAN_OK;
+}
+
+
+// weight gradient on 16-bit x AND dy (Cout % 128 == 0, Cin % 128 == 0, no upsample): dw += ..., db += ... (db may be null)
+bool conv_wgrad16s_ok(const ConvGeom& g) { return wgrad16s_shape_ok(g); }
+size_t conv_wgrad16s_scratch_bytes(const ConvGeom& g) {
+    if (!wgrad16s_shape_ok(g)) return 0;
+    const WgSPlan q = wgrad16s_plan(g);
+    return q.part_bytes + q.partb_bytes;
+}
+int conv_wgrad16s(const ConvGeom& g, int dtype, const void* x16, const void* dy16, float* dw, float* db, void* scratch, hipStream_t st) {
+    if (!wgrad16s_shape_ok(g) || !dw) return ACLGAN_EUNSUPPORTED;
+    ACL_REQUIRE(x16 && dy16 && scratch, "conv_wgrad16s: null operand / scratch");
+    ACL_REQUIRE((long long)g.B * g.Hi * g.Wi * g.Ci * 2 < 0x7fffffe0ll && (long long)g.M * g.Co * 2 < 0x7fffffe0ll, "conv_wgrad16s: operand beyond 2 GB");
+    const WgSPlan q = wgrad16s_plan(g);
+    WgSP p;
+    p.x16 = (const u16*)x16; p.dy16 = (const u16*)dy16; p.part = (float*)scratch; p.part_b = (float*)((char*)scratch + q.part_bytes); p.dw = dw; p.db = db;
+    p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p; p.P = g.M; p.Kn = g.K;
+    p.chunk = q.chunk; p.tiles_n = q.tiles_n; p.nwg = q.nwg; p.splits = q.splits; p.nsub = q.nsub; p.sub = q.sub;
+    if (dtype == ACLGAN_DTYPE_BF16) hipLaunchKernelGGL(conv_wgrad16s_kernel<QBF16>, dim3(q.nwg, 1, q.splits), dim3(256), 0, st, p);
+    else if (dtype == ACLGAN_DTYPE_FP16) hipLaunchKernelGGL(conv_wgrad16s_kernel<QFP16>, dim3(q.nwg, 1, q.splits), dim3(256), 0, st, p);
+    else { set_error("conv_wgrad16s: dtype %d", dtype); return ACLGAN_EINVAL; }
+    ACL_CHECK_LAUNCH("conv_wgrad16s_kernel");
+    if (db) {
+        hipLaunchKernelGGL(colsum16_kernel, dim3(g.Co / 64, q.nsub), dim3(256), 0, st, p, dtype);
+        ACL_CHECK_LAUNCH("colsum16_kernel");
+    }
+    hipLaunchKernelGGL(wgrad16s_finish_kernel, dim3((int)std::min<int64_t>(cdiv64((int64_t)g.Co * (g.K / 4), 256), 4096)), dim3(256), 0, st, p);
+    ACL_CHECK_LAUNCH("wgrad16s_finish_kernel");
     return ACLGAN_OK;
 }
 

@@ -116,12 +116,60 @@ struct aclgan_ctx {
     static bool act16_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ACLGAN_ACT16"); v = (e && !atoi(e)) ? 0 : 1; } return v == 1; }
     static bool co16_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ACLGAN_CO16"); v = e ? (atoi(e) ? 1 : 0) : 1; } return v == 1; }
 
-    ~aclgan_ctx() { reset_step(); }
+    // Side stream of the backward (round 3): the weight gradient of a layer depends only on tensors that stay put until the update
+    // ends (x, dy, the kept Winograd transform) and nothing in the backward waits for it, while the input gradient is on the critical
+    // path -- so the weight-gradient pipeline of layer L (transforms: HBM-bound, GEMM: MFMA-bound, finishes: latency-bound) runs on a
+    // second stream next to the input-gradient pipeline of L and the norm backward of L-1, filling each other's tails and dispatch
+    // gaps.  Fork = an event on the main stream after dy is complete; join = before a gradient bucket is handed to the all-reduce and
+    // at the end of the tape.  Its scratch is a second stack growing down from the END of the workspace (stream-ordered reuse).
+    // ACLGAN_SIDE_STREAM=0 turns it off (everything on the caller's stream, as in round 2).
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_pending = false;
+    size_t top2 = 0, peak2 = 0;
+    static bool side_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ACLGAN_SIDE_STREAM"); v = (e && !atoi(e)) ? 0 : 1; } return v == 1; }
+    void* alloc2(size_t bytes) {
+        const size_t need = top2 + ((bytes + 255) & ~(size_t)255);
+        top2 = need;
+        if (need > peak2) peak2 = need;
+        if (dry) return (void*)(uintptr_t)4096;
+        if (top + need > ws_bytes) return nullptr;
+        return ws + ((ws_bytes - need) & ~(size_t)255);
+    }
+    int side_fork() {       // the side stream may start once everything enqueued on the main stream so far is done
+        if (dry) return ACLGAN_OK;
+        if (!st2) {
+            hipError_t e = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+            if (e != hipSuccess) return aclgan::hip_fail(e, "side stream");
+        }
+        hipError_t e = hipEventRecord(ev_fork, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st2, ev_fork, 0);
+        if (e != hipSuccess) return aclgan::hip_fail(e, "side stream fork");
+        side_pending = true;
+        return ACLGAN_OK;
+    }
+    int side_join() {       // the main stream waits for everything the side stream was given
+        if (dry || !side_pending) return ACLGAN_OK;
+        hipError_t e = hipEventRecord(ev_join, st2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);
+        if (e != hipSuccess) return aclgan::hip_fail(e, "side stream join");
+        side_pending = false;
+        return ACLGAN_OK;
+    }
+    ~aclgan_ctx() {
+        reset_step();
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (st2) (void)hipStreamDestroy(st2);
+    }
     void reset_step() {
         for (Act* a : acts) delete a;
         acts.clear();
         tape.clear();
         top = 0;
+        top2 = 0;
         keep_total = 0;
     }
     void* alloc(size_t bytes) {
@@ -400,7 +448,14 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         c.count((es_co + eg_out + eg_co) * (double)co->numel() + ((residual && residual->need_grad) ? (residual->gdt ? 2.0 : 4.0) * (double)co->numel() : 0.0));
         if (train_w) c.count(es_in * (double)in->numel() + eg_co * (double)co->numel() + 4.0 * ((double)Co * g.K + Co));
         if (gin->need_grad) c.count(eg_co * (double)co->numel() + es_w * (double)Co * g.K + eg_in * (double)in->numel());
-        const size_t mark0 = c.top;
+        const bool side = train_w && aclgan_ctx::side_enabled();      // this layer's weight gradient goes to the side stream
+        float* g16 = nullptr;
+        const size_t mark_pre = c.top;
+        if (!has_norm && s_bwd && out->gdt == 0) {      // (with the side stream: kept below the closure's scratch mark -- that stream may read it later)
+            g16 = (float*)c.alloc((size_t)out->numel() * 2);
+            NEED(g16);
+        }
+        const size_t mark0 = side ? c.top : mark_pre;
         const float* dyp = nullptr;       // gradient w.r.t. the conv output, as the dgrad / wgrad kernels read it
         int dy_st = 0;
         if (has_norm) {
@@ -416,8 +471,6 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             dyp = co->g; dy_st = co->gdt;
         } else if (s_bwd && out->gdt == 0) {
             // the consumers delivered an fp32 gradient, this layer's backward kernels read 16-bit: dy16 = act'(y) * dy, out of place
-            float* g16 = (float*)c.alloc((size_t)out->numel() * 2);
-            NEED(g16);
             RUN(cast_storage(out->g, 0, g16, dt, out->numel(), c.st));
             RUN(act_bwd_inplace(act, out->d, g16, out->numel(), c.st, out->dt, dt));
             dyp = g16; dy_st = dt;
@@ -429,11 +482,17 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             const size_t mark = c.top;
             void* wscr = nullptr;
             const size_t wb = w16 ? conv_wgrad16_scratch_bytes(g) : conv_wgrad_scratch_bytes(g);
-            if (wb) { wscr = c.alloc(wb); NEED(wscr); }
-            if (w16) RUN(conv_wgrad16(g, dt, in->d, dyp, W.dw, W.db, wscr, c.st, in->dt, dy_st));
+            hipStream_t wst = c.st;
+            if (side) {
+                CHK(c.side_fork());
+                if (!c.dry) wst = c.st2;
+                c.top2 = 0;                   // side-stream work is stream-ordered: its scratch stack restarts with every launch group
+                if (wb) { wscr = c.alloc2(wb); if (!wscr) { set_error("workspace too small for the side-stream scratch"); return ACLGAN_ENOMEM; } }
+            } else if (wb) { wscr = c.alloc(wb); NEED(wscr); }
+            if (w16) RUN(conv_wgrad16(g, dt, in->d, dyp, W.dw, W.db, wscr, wst, in->dt, dy_st));
             else {
                 if (in->dt || dy_st) { set_error("conv_block: fp32 weight-gradient kernel on 16-bit operands"); return ACLGAN_EINVAL; }
-                RUN(conv_wgrad(g, in->d, dyp, W.dw, W.db, c.st, wscr, keepV));
+                RUN(conv_wgrad(g, in->d, dyp, W.dw, W.db, wst, wscr, keepV));
             }
             c.top = mark;
         }
@@ -793,9 +852,12 @@ static int run_tape(aclgan_ctx& c) {
     }
     for (size_t i = n; i-- > 0;) {
         CHK(c.tape[i].fn());
-        if (buckets) for (int b : done_at[i]) fire_bucket(c, b);
+        if (buckets && !done_at[i].empty()) {
+            CHK(c.side_join());             // a bucket handed to the all-reduce must hold its side-stream weight gradients too
+            for (int b : done_at[i]) fire_bucket(c, b);
+        }
     }
-    return ACLGAN_OK;
+    return c.side_join();
 }
 
 static int check_shape(const aclgan_ctx& c, int B, int H, int W) {
@@ -1032,11 +1094,11 @@ int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out) {
     size_t best = 0;
     for (int which = 0; which < 2; ++which) {
         c.reset_step();
-        c.dry = true; c.peak = 0; c.trained = -1;
+        c.dry = true; c.peak = 0; c.peak2 = 0; c.trained = -1;
         int rc = which == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)
                             : dis_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr);
-        c.dry = false;
-        const size_t pk = c.peak;
+        c.dry = false; c.trained = -1;
+        const size_t pk = c.peak + c.peak2 + 512;
         c.reset_step();
         if (rc) return rc;
         if (pk > best) best = pk;

@@ -170,11 +170,20 @@ def test_conv_wgrad16_any_storage(L, case, dt, stx, stdy):
     # bias gradient: summed from dy as stored (fp32 dy: unrounded; 16-bit dy: the rounded values, which is what br.grad saw)
     want_db = br.grad if stdy else dy.double().sum(dim=(0, 2, 3))
     assert _rel(db, want_db) < EXACT_TOL
-    # identical bits to the fp32-storage call on pre-rounded operands
+    # the same numbers from the fp32-storage call on pre-rounded operands (bitwise when the same kernel ran; with both operands 16-bit and
+    # Cin, Cout multiples of 128 the pixel-major LDS-DMA kernel runs instead: other summation order)
     dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
     xr32, dyr32 = xg.to(TDT[dt]).float(), (dyg.to(TDT[dt]).float() if stdy else dyg)
     L.check(L.lib.aclgan_conv2d_wgrad16_st(C.byref(d), code, L.ptr(xr32), 0, L.ptr(dyr32), 0, L.ptr(dw2), L.ptr(db2), L.ptr(scr), L.stream_ptr()))
-    assert torch.equal(dw, dw2)
+    if stx and stdy and Ci % 128 == 0 and Co % 128 == 0 and not up:
+        assert _rel(dw, dw2) < 1e-5
+    else:
+        assert torch.equal(dw, dw2)
+    # reproducible bit for bit either way (ordered slices)
+    dw3 = torch.zeros_like(dw); db3 = torch.zeros_like(db)
+    L.check(L.lib.aclgan_conv2d_wgrad16_st(C.byref(d), code, L.ptr(xs), code if stx else 0, L.ptr(dys), code if stdy else 0, L.ptr(dw3), L.ptr(db3),
+                                           L.ptr(scr), L.stream_ptr()))
+    assert torch.equal(dw, dw3) and torch.equal(db, db3)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
