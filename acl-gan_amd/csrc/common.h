@@ -84,6 +84,15 @@ int conv_dgrad_fast(const ConvGeom& g, const float* dy, const float* w, float* d
 int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, hipStream_t st, void* scratch = nullptr, const float* haveV = nullptr);
 size_t conv_wgrad_fast_scratch_bytes(const ConvGeom& g);
 
+// Winograd filter-transform cache (round 3): a generator's ResBlock filters are transformed 2-3 times per update (the decoder runs up
+// to three times, forward and input-gradient each need U) -- the step scheduler offers a per-update cache instead.  lookup(w, variant,
+// bytes, &fresh): the buffer that holds / shall hold the transform of filter tensor w (variant 0 forward, 1 flipped for the input
+// gradient, 2 / 3 the same for the merged sub-pixel phase filters); fresh = it must be computed by the caller now.  nullptr: not cached.
+struct WinoUCache { void* user; float* (*lookup)(void* user, const float* w, int variant, size_t bytes, bool* fresh); };
+void set_wino_ucache(const WinoUCache* c);      // thread-local; nullptr = off (operator-level calls)
+const WinoUCache* wino_ucache();
+size_t conv_wino_u_bytes(const ConvGeom& g);    // bytes of one cached transform of this layer's filter (0: not a Winograd layer)
+
 // Winograd F(4x4,3x3) path of the 3x3 stride-1 reflect-pad-1 layers (conv_wino.hip); EUNSUPPORTED when not eligible / no scratch
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_scratch_bytes(const ConvGeom& g);
@@ -98,8 +107,13 @@ bool conv_up5_wino_ok(const ConvGeom& g);
 size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g);
 size_t conv_up5_wino_dgrad_scratch_bytes(const ConvGeom& g);
 size_t conv_up5_wino_wgrad_scratch_bytes(const ConvGeom& g);
-int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV = nullptr);
-int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st);
+// wkey (optional): the ORIGINAL 5x5 filter tensor the merged phase filters wp were made from -- the key of the filter-transform cache
+int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV = nullptr,
+                             const float* wkey = nullptr);
+int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st,
+                               const float* wkey = nullptr);
+// true: the cache already holds that transform (the caller may skip preparing wp)
+bool wino_u_cached(const float* wkey, int variant);
 int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* dy, float* dwp, float* db, void* scratch, hipStream_t st, const float* haveV = nullptr);
 size_t conv_up5_dgrad_scratch_bytes(const ConvGeom& g);
 int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, const float* haveV = nullptr);
@@ -124,7 +138,9 @@ int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, 
 // 16-bit ACTIVATION STORAGE kernels (conv_glds16.hip): operands already live in HBM in the 16-bit dtype, tiles go global -> LDS directly.
 // which: 0 forward, 1 dgrad.  No upsample, Cin % 64 == 0, Cout % 64 == 0.
 bool conv16s_ok(const ConvGeom& g, int which);
-int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st);
+// stats (optional, conv_fwd16s_stats_chunk(g) > 0): [B][Ho*Wo / chunk][Co] (mean, M2) pairs of the STORED outputs -- norm_fwd's chunk partials
+int conv_fwd16s_stats_chunk(const ConvGeom& g);
+int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st, float* stats = nullptr);
 size_t conv_dgrad16s_scratch_bytes(const ConvGeom& g);
 // weight gradient with BOTH operands in the 16-bit dtype (Cin, Cout multiples of 128): pixel-major LDS-DMA tiles + transposing LDS reads
 bool conv_wgrad16s_ok(const ConvGeom& g);

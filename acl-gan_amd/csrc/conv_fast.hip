@@ -954,8 +954,10 @@ size_t wgrad_fast_det_bytes(const ConvGeom& g, int Kn, int P, int ny) {
 template <int WM, int WN, int TM, int TN>
 int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, float* wp, hipStream_t st, float* keepV) {
     const int64_t nm = (int64_t)4 * g.Co * 9 * (g.Ci / 4);
-    hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
-    ACL_CHECK_LAUNCH("up5_merge_kernel");
+    if (!(conv_up5_wino_ok(g) && wino_u_cached(w, 2))) {      // (the Winograd phases read only the cached transform of the merged filters)
+        hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
+        ACL_CHECK_LAUNCH("up5_merge_kernel");
+    }
     FwdFP p;
     p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;
     // (1) the four phases: valid 3x3 conv on the low-res input, scattered into the 2H x 2W output
@@ -969,7 +971,7 @@ int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bi
     // the merged filters and the ring partials
     char* wino_scr = (char*)wp + up5_merged_bytes(g) + ((fwd_partial_bytes(g, 2, BK) + 255) & ~(size_t)255);
     if (keepV && !conv_up5_wino_ok(g)) { set_error("conv_fwd: this layer does not keep a Winograd input transform"); return ACLGAN_EINVAL; }
-    int rc = conv_up5_wino_ok(g) ? conv_up5_wino_fwd_phases(g, x, wp, bias, y, wino_scr, st, keepV) : launch_fwd_fast<WM, WN, TM, TN>(gp, p, st);
+    int rc = conv_up5_wino_ok(g) ? conv_up5_wino_fwd_phases(g, x, wp, bias, y, wino_scr, st, keepV, w) : launch_fwd_fast<WM, WN, TM, TN>(gp, p, st);
     if (rc) return rc;
     // (2) the output ring of width 2: exact gather (reflection at the borders of the upsampled image)
     p.w = w;
@@ -1014,8 +1016,10 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
 template <int WM, int WN, int TM, int TN>
 int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, float* wp, hipStream_t st) {
     const int64_t nm = (int64_t)4 * g.Co * 9 * (g.Ci / 4);
-    hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
-    ACL_CHECK_LAUNCH("up5_merge_kernel");
+    if (!(conv_up5_wino_ok(g) && wino_u_cached(w, 3))) {
+        hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
+        ACL_CHECK_LAUNCH("up5_merge_kernel");
+    }
     // (1) four phases: dgrad of the VALID 3x3 conv on the low-res grid, read through the phase view of dy,
     //     accumulated straight into dx (plain read-modify-write: the launches are stream-ordered)
     ConvGeom gv = g;
@@ -1028,7 +1032,7 @@ int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, i
     p.mode = 1; p.pad = 0; p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi;
     p.dyv = 1; p.Hf = g.Ho; p.Wf = g.Wo; p.band = 0; p.upshift = 0; p.Hd = g.Hi; p.Wd = g.Wi;
     if (conv_up5_wino_ok(g)) {       // Winograd: full correlation of the four phase views of dy with the flipped merged filters
-        const int rc = conv_up5_wino_dgrad_phases(g, dy, wp, dx, accumulate, (char*)wp + up5_merged_bytes(g), st);
+        const int rc = conv_up5_wino_dgrad_phases(g, dy, wp, dx, accumulate, (char*)wp + up5_merged_bytes(g), st, w);
         if (rc) return rc;
     } else for (int ph = 0; ph < 4; ++ph) {
         p.w = wp + (size_t)ph * g.Co * 9 * g.Ci;
@@ -1133,6 +1137,9 @@ int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, in
             hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 1, 3>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
         } else if (var == 2) {
             hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 2, 2, 3>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
+        } else if (var == 3 && N % 256 == 0) {      // 64 x 256 tiles: a workgroup covers all of N = 256, V is fetched once per row tile
+            p.tiles_n = N / 256; p.nwg = cdiv(T, 64) * p.tiles_n;
+            hipLaunchKernelGGL((conv_fwd_fast_kernel<1, 4, 2, 2, 3>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);
         } else {
             p.tiles_n = cdiv(N, 128); p.nwg = cdiv(T, 64) * p.tiles_n;
             hipLaunchKernelGGL((conv_fwd_fast_kernel<2, 2, 1, 2, 4>), dim3(p.nwg, nslices, 1), dim3(256), 0, st, p);

@@ -54,7 +54,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7fffffe0ll ? 0x7fffffe0ll : bytes), 0x00020000);
 }
 
-// one k-tile of MFMAs from LDS buffers a (this wave's 64 rows start at row ra) and b (rows rb): TM x TN tiles, 4 k-steps of 16
+// one k-tile of MFMAs from LDS buffers a (this wave's 64 rows) and b: TM x TN tiles, 4 k-steps of 16.  All 16 fragment reads are issued
+// up front (hipcc interleaves their lgkmcnt waits with the MFMAs).  Measured and rejected (profiles/r03_experiments.md): reading the
+// fragments per k-step and issuing the next tile's DMA pieces behind each k-step's MFMAs (sched_barrier-pinned) -- the exposed ds_read
+// latency costs far more than the DMA issue slots it hides (forward 53 -> 59 us, weight gradient 125 -> 150 us).
 template <class T, int TM, int TN>
 __device__ __forceinline__ void mma_tile(const unsigned char* a, const unsigned char* b, int lane, f32x16 (&acc)[TM][TN]) {
     const int l31 = lane & 31, kh = lane >> 5;
@@ -168,9 +171,10 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(Fwd
     int avo[4];
     int f_tap = -1;
 
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    int soff_a = 0, soff_b = 0;
+    auto setup = [&](int kt) __attribute__((always_inline)) {      // gather offsets of k-tile kt (block-uniform branch at a new filter tap)
         const int tap = kt / cpt, cc = kt - tap * cpt;
-        if (tap != f_tap) {                        // block-uniform: new filter tap -> redo the gather offsets
+        if (tap != f_tap) {
             f_tap = tap;
             const int ky = tap / p.k, kx = tap - ky * p.k;
 #pragma unroll
@@ -179,12 +183,18 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(Fwd
                 avo[n] = ((ab[n] + iy * p.Wi + ix) * p.Ci + acs[n]) * 2;
             }
         }
+        soff_a = cc * 128; soff_b = kt * 128;
+    };
+    auto piece = [&](int n, int buf) __attribute__((always_inline)) {   // DMA piece n of the A tile and (n < B_IT) of the B tile into buffer buf
         unsigned char* da = smem + buf * A_BYTES + (32 * wave) * ROWB;
         unsigned char* db = smem + NBUF * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], soff_a, 0, 0);
+        if (n < B_IT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n < B_IT ? n : 0], soff_b, 0, 0);
+    };
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        setup(kt);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
-#pragma unroll
-        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], kt * 128, 0, 0);
+        for (int n = 0; n < 4; ++n) piece(n, buf);
     };
 
     f32x16 acc[TM][TN];
@@ -214,8 +224,50 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(Fwd
 
     const float* bias = p.bias;
     const int act = p.act;
-    store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Co, p.Co, p.y, p.yst, lane,
-                      [&](float v, int n) { return act_apply(v + (bias ? bias[n] : 0.f), act); });
+    if (p.stats) {
+        // Normalisation statistics from the epilogue (block-uniform; the launcher offers it only when every tile is 128 full rows of one
+        // sample): (mean, M2) of the 128 STORED outputs of each channel of this tile = one chunk partial of norm_finalize_*.  A lane holds
+        // 2 x 16 rows of each of its TN columns; lanes l / l ^ 32 and the two row-halves of the workgroup (waves wm = 0 / 1) are merged
+        // with Chan's formula for equal counts.
+        const int l31 = lane & 31, lh = lane >> 5;
+        float2* red = reinterpret_cast<float2*>(smem);
+        __syncthreads();                           // every wave is done with the operand buffers
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+            const float bv = (bias && n < p.Co) ? bias[n] : 0.f;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = act_apply(acc[i][j][r] + bv, act);
+                    if (p.yst != ST_F32) v = st_unpack2(st_pack2(v, 0.f, p.yst), p.yst)[0];     // the value as it will be stored
+                    acc[i][j][r] = v;
+                    sum += v;
+                }
+            float mean = sum * (1.f / 32.f), q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float dv = acc[i][j][r] - mean; q += dv * dv; }
+            const float om = __shfl_xor(mean, 32), oq = __shfl_xor(q, 32);
+            const float dm = om - mean;
+            q = q + oq + dm * dm * 16.f;           // n_a n_b / (n_a + n_b) = 32 * 32 / 64
+            mean = 0.5f * (mean + om);
+            if (lh == 0) red[wm * BN + wn * (BN / 2) + j * 32 + l31] = make_float2(mean, q);
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Co) {
+            const float2 a = red[tid], b2 = red[BN + tid];
+            const float dm = b2.x - a.x;
+            p.stats[(size_t)(m0 / BM) * p.Co + n0 + tid] = make_float2(0.5f * (a.x + b2.x), a.y + b2.y + dm * dm * 32.f);
+        }
+        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Co, p.Co, p.y, p.yst, lane, [](float v, int) { return v; });
+    } else {
+        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Co, p.Co, p.y, p.yst, lane,
+                          [&](float v, int n) { return act_apply(v + (bias ? bias[n] : 0.f), act); });
+    }
 #endif
 }
 
@@ -299,7 +351,8 @@ __global__ void __launch_bounds__(256, 2) conv_dgrad16s_kernel(DgSP p) {
     int avo[4];
     int f_tap = -1, tapoff = 0;
 
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    int soff_a = 0, soff_b = 0;
+    auto setup = [&](int kt) __attribute__((always_inline)) {
         const int t = kt / cpt, cc = kt - t * cpt;
         if (t != f_tap) {
             f_tap = t;
@@ -312,12 +365,18 @@ __global__ void __launch_bounds__(256, 2) conv_dgrad16s_kernel(DgSP p) {
                 avo[n] = ok ? (((ab[n] * p.Ho + oy) * p.Wo + ox) * p.Co + acs[n]) * 2 : OOB;
             }
         }
+        soff_a = cc * 128; soff_b = tapoff + cc * 128;
+    };
+    auto piece = [&](int n, int buf) __attribute__((always_inline)) {
         unsigned char* da = smem + buf * A_BYTES + (32 * wave) * ROWB;
         unsigned char* db = smem + 2 * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], soff_a, 0, 0);
+        if (n < B_IT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n < B_IT ? n : 0], soff_b, 0, 0);
+    };
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        setup(kt);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
-#pragma unroll
-        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], tapoff + cc * 128, 0, 0);
+        for (int n = 0; n < 4; ++n) piece(n, buf);
     };
 
     f32x16 acc[TM][TN];
@@ -451,29 +510,30 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad16s_kernel(WgSP p) {
         }
         __syncthreads();
         const int nkt = (ce - cb + BK - 1) / BK;
-        auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        auto piece = [&](int kt, int n, int buf) __attribute__((always_inline)) {      // pixel rows 16 wave + 4 n .. + 3 of both operand tiles
             unsigned char* da = smem + buf * 2 * T_BYTES + (16 * wave) * PROW;
             unsigned char* db = da + T_BYTES;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int pl = kt * BK + 16 * wave + 4 * n + lp;
-                const int sp = pinfo[pl];
-                const int va = sp >= 0 ? ((cb + pl) * p.Co + m0) * 2 + swz : OOB;
-                const int vb = sp >= 0 ? (sp * p.Ci + ci0) * 2 + swz : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 4 * PROW), 16, va, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(db + n * 4 * PROW), 16, vb, 0, 0, 0);
-            }
+            const int pl = kt * BK + 16 * wave + 4 * n + lp;
+            const int sp = pinfo[pl];
+            const int va = sp >= 0 ? ((cb + pl) * p.Co + m0) * 2 + swz : OOB;
+            const int vb = sp >= 0 ? (sp * p.Ci + ci0) * 2 + swz : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 4 * PROW), 16, va, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(db + n * 4 * PROW), 16, vb, 0, 0, 0);
         };
-        issue(0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) piece(0, n, 0);
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             __syncthreads();
-            if (kt + 1 < nkt) issue(kt + 1, cur ^ 1);
+            if (kt + 1 < nkt) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) piece(kt + 1, n, cur ^ 1);
+            }
             const unsigned char* ta = smem + cur * 2 * T_BYTES;
             const unsigned char* tb = ta + T_BYTES;
+            u32x4 fa[4][2], fb[4][2];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                u32x4 fa[2], fb[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ta + fo_a[t] + ks * 16 * PROW));
@@ -482,14 +542,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad16s_kernel(WgSP p) {
                     const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb + fo_b[t] + ks * 16 * PROW + 4 * PROW));
                     const uint2 a0u = __builtin_bit_cast(uint2, a0), a1u = __builtin_bit_cast(uint2, a1);
                     const uint2 b0u = __builtin_bit_cast(uint2, b0), b1u = __builtin_bit_cast(uint2, b1);
-                    fa[t] = (u32x4){a0u.x, a0u.y, a1u.x, a1u.y};
-                    fb[t] = (u32x4){b0u.x, b0u.y, b1u.x, b1u.y};
+                    fa[ks][t] = (u32x4){a0u.x, a0u.y, a1u.x, a1u.y};
+                    fb[ks][t] = (u32x4){b0u.x, b0u.y, b1u.x, b1u.y};
                 }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
-            }
+                    for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[ks][i], fb[ks][j], acc[i][j]);
         }
         __syncthreads();       // the gather table and both buffers are free for the next sub-chunk
     }
@@ -562,7 +624,11 @@ WgSPlan wgrad16s_plan(const ConvGeom& g) {
 bool wgrad16s_shape_ok(const ConvGeom& g) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("ACLGAN_NOWGRAD16S"); off = (e && atoi(e)) ? 1 : 0; }
-    return !off && enabled() && shape_ok(g) && g.Co % 128 == 0 && g.Ci % 128 == 0 && g.M >= 64;
+    // (pays once the pixel axis is long: B=8, 64x64 maps 125 us vs 120 us for the register-transposing kernel, B=32 258 vs 411 us;
+    //  ACLGAN_WGRAD16S_MINPIX overrides the threshold)
+    static int minpix = -1;
+    if (minpix < 0) { const char* e = getenv("ACLGAN_WGRAD16S_MINPIX"); minpix = e ? atoi(e) : 65536; }
+    return !off && enabled() && shape_ok(g) && g.Co % 128 == 0 && g.Ci % 128 == 0 && g.M >= std::max(64, minpix);
 }
 
 bool shape_ok(const ConvGeom& g) {
@@ -590,12 +656,20 @@ bool conv16s_ok(const ConvGeom& g, int which) {
     return true;
 }
 
-int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st) {
+// > 0: conv_fwd16s can emit the normalisation statistics of its output ((mean, M2) per 128-pixel chunk and channel) from its epilogue
+int conv_fwd16s_stats_chunk(const ConvGeom& g) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ACLGAN_NOSTATFUSE"); off = (e && atoi(e)) ? 1 : 0; }
+    return (!off && conv16s_ok(g, 0) && (g.Ho * g.Wo) % 128 == 0) ? 128 : 0;
+}
+
+int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st, float* stats) {
     if (!conv16s_ok(g, 0)) return ACLGAN_EUNSUPPORTED;
+    if (stats && !conv_fwd16s_stats_chunk(g)) { set_error("conv_fwd16s: statistics are not offered for this shape"); return ACLGAN_EINVAL; }
     ACL_REQUIRE(x16 && w16 && y, "conv_fwd16s: null operand");
     ACL_REQUIRE((long long)g.B * g.Hi * g.Wi * g.Ci * 2 < 0x7fffffe0ll && (long long)g.Co * g.K * 2 < 0x7fffffe0ll, "conv_fwd16s: operand beyond 2 GB");
     FwdSP p;
-    p.x16 = (const u16*)x16; p.w16 = (const u16*)w16; p.bias = bias; p.y = y; p.yst = yst; p.stats = nullptr;
+    p.x16 = (const u16*)x16; p.w16 = (const u16*)w16; p.bias = bias; p.y = y; p.yst = yst; p.stats = (float2*)stats;
     p.B = g.B; p.Hi = g.Hi; p.Wi = g.Wi; p.Ci = g.Ci; p.Ho = g.Ho; p.Wo = g.Wo; p.Co = g.Co; p.k = g.k; p.s = g.s; p.p = g.p;
     p.M = g.M; p.K = g.K; p.act = g.act; p.tiles_n = 0; p.nwg = 0;
     if (dtype == ACLGAN_DTYPE_BF16) return launch_fwd16s<QBF16>(g, p, st);

@@ -27,7 +27,26 @@ int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, in
 size_t gemm_at_b_slices_scratch(int T, int M, int N, int nslices);
 int gemm_at_b_slices_f32(const float* A, const float* Bm, float* Cm, int T, int M, int N, int nslices, int b_mod, void* part, hipStream_t st);
 
+static thread_local const WinoUCache* g_ucache = nullptr;
+void set_wino_ucache(const WinoUCache* c) { g_ucache = c; }
+const WinoUCache* wino_ucache() { return g_ucache; }
+bool wino_u_cached(const float* wkey, int variant) {
+    if (!g_ucache || !wkey) return false;
+    bool fresh = true;
+    float* u = g_ucache->lookup(g_ucache->user, wkey, variant, 0, &fresh);
+    return u != nullptr && !fresh;
+}
+
 namespace {
+
+// U of filter tensor `key` from the cache when the scheduler offers one (fresh: compute it now), else the scratch slice
+float* cached_u(float* scratch_u, const float* key, int variant, size_t bytes, bool* fresh) {
+    *fresh = true;
+    if (!g_ucache || !key) return scratch_u;
+    float* u = g_ucache->lookup(g_ucache->user, key, variant, bytes, fresh);
+    if (!u) { *fresh = true; return scratch_u; }
+    return u;
+}
 
 __device__ __forceinline__ int reflw(int v, int n) {
     v = v < 0 ? -v : v;
@@ -456,6 +475,11 @@ bool conv_wino_ok(const ConvGeom& g) {
     return wino_enabled() && g.k == 3 && g.s == 1 && g.p == 1 && g.up == 0 && g.Ho % 4 == 0 && g.Wo % 4 == 0 && g.Ci % 16 == 0 && g.Co % 16 == 0 &&
            (int64_t)g.Ci * g.Co >= 64 * 64;
 }
+size_t conv_wino_u_bytes(const ConvGeom& g) {
+    if (conv_wino_ok(g)) return align256((size_t)36 * g.Co * g.Ci * sizeof(float));
+    if (conv_up5_wino_ok(g)) return align256((size_t)144 * g.Co * g.Ci * sizeof(float));
+    return 0;
+}
 size_t conv_wino_scratch_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g)) return 0;
     const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
@@ -474,8 +498,12 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
     float* M = take(cur, (size_t)36 * T * Cout_ * 4);
     if (keepV) V = keepV;         // the caller keeps the input transform for the weight gradient of the same layer
     const WViews vw = one_view(ident_view(H, W));
-    hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip);
-    ACL_CHECK_LAUNCH("wino_filter_kernel");
+    bool fresh = true;
+    U = cached_u(U, w, flip ? 1 : 0, (size_t)36 * Cout_ * Cin_ * 4, &fresh);
+    if (fresh) {
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip);
+        ACL_CHECK_LAUNCH("wino_filter_kernel");
+    }
     int rc = launch_wino_input(in, V, B, vw, 1, Cin_, TY, TX, -1, reflect, st);
     if (rc) return rc;
     rc = gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, 0, st);
@@ -569,7 +597,8 @@ size_t conv_up5_wino_keep_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     return align256((size_t)36 * up5_geo(g).T * g.Ci * sizeof(float));
 }
-int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV) {
+int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV,
+                             const float* wkey) {
     if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
@@ -577,8 +606,12 @@ int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp,
     float* V = take(cur, (size_t)36 * q.T * g.Ci * 4);
     float* M = take(cur, (size_t)144 * q.T * g.Co * 4);
     if (keepV) V = keepV;
-    hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0);
-    ACL_CHECK_LAUNCH("wino_filter_kernel(up5)");
+    bool fresh = true;
+    U = cached_u(U, wkey, 2, (size_t)144 * g.Co * g.Ci * 4, &fresh);
+    if (fresh) {
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0);
+        ACL_CHECK_LAUNCH("wino_filter_kernel(up5)");
+    }
     int rc = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
     if (rc) return rc;
     rc = gemm_slices_f32(V, U, M, (int)q.T, g.Ci, g.Co, 144, 36, st);      // the 4 phases share V: A offset = (f % 36) planes
@@ -591,15 +624,19 @@ size_t conv_up5_wino_dgrad_scratch_bytes(const ConvGeom& g) {
     const Up5Geo q = up5_geo(g);
     return align256((size_t)144 * g.Co * g.Ci * 4) + align256((size_t)144 * q.Td * g.Co * 4) + align256((size_t)144 * q.Td * g.Ci * 4) + 256;
 }
-int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st) {
+int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st, const float* wkey) {
     if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
     float* U = take(cur, (size_t)144 * g.Co * g.Ci * 4);
     float* V = take(cur, (size_t)144 * q.Td * g.Co * 4);
     float* M = take(cur, (size_t)144 * q.Td * g.Ci * 4);
-    hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1);
-    ACL_CHECK_LAUNCH("wino_filter_kernel(up5 dgrad)");
+    bool fresh = true;
+    U = cached_u(U, wkey, 3, (size_t)144 * g.Co * g.Ci * 4, &fresh);
+    if (fresh) {
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1);
+        ACL_CHECK_LAUNCH("wino_filter_kernel(up5 dgrad)");
+    }
     // dx[u] = sum_k wflip[k] dy_phase[u - 2 + k]: patches start 2 before the tile, zero outside the 62 x 62 phase view
     int rc = launch_wino_input(dy, V, g.B, q.ph, 4, g.Co, q.TYd, q.TXd, -2, 0, st);
     if (rc) return rc;

@@ -110,6 +110,28 @@ struct aclgan_ctx {
     double alg_bytes = 0.0;
     void count(double bytes) { alg_bytes += bytes; }
     size_t keep_total = 0;      // bytes of Winograd input transforms kept for the weight gradients of this update (conv_block)
+    // Winograd filter transforms of this update, by (filter tensor, variant): computed by the first layer call that needs one, reused by
+    // the later calls of the same network (common.h: WinoUCache); the buffers live in the arena until the update ends
+    struct UEnt { float* u; bool filled; };
+    std::map<std::pair<const float*, int>, UEnt> ucache;
+    WinoUCache ucache_hook;
+    static bool ucache_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ACLGAN_NOUCACHE"); v = (e && atoi(e)) ? 0 : 1; } return v == 1; }
+    static float* ucache_lookup(void* user, const float* w, int variant, size_t bytes, bool* fresh) {
+        aclgan_ctx* c = (aclgan_ctx*)user;
+        auto it = c->ucache.find(std::make_pair(w, variant));
+        if (it == c->ucache.end()) return nullptr;       // not reserved (operator-level call paths): the caller uses its scratch slice
+        *fresh = !it->second.filled;
+        if (bytes) it->second.filled = true;             // (bytes == 0: a peek)
+        return it->second.u;
+    }
+    // make sure the arena holds a slot for the transform of (w, variant); call where an allocation may persist until the update ends
+    int ucache_reserve(const float* w, int variant, size_t bytes) {
+        if (!ucache_enabled() || !bytes || ucache.count(std::make_pair(w, variant))) return ACLGAN_OK;
+        float* u = (float*)alloc(bytes);
+        if (!u) return ACLGAN_ENOMEM;
+        ucache[std::make_pair(w, variant)] = UEnt{u, false};
+        return ACLGAN_OK;
+    }
     // 16-bit activation / gradient storage of the wide layers (C % 64 == 0) under a 16-bit compute dtype; co16: also the conv outputs
     // that feed a normalisation layer (ACLGAN_ACT16=0 / ACLGAN_CO16=0|1 switch them)
     bool act16() const { return dtype != ACLGAN_DTYPE_FP32 && act16_enabled(); }
@@ -171,6 +193,7 @@ struct aclgan_ctx {
         top = 0;
         top2 = 0;
         keep_total = 0;
+        ucache.clear();
     }
     void* alloc(size_t bytes) {
         const size_t a = (top + 255) & ~(size_t)255;
@@ -408,12 +431,14 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         const size_t kb = conv_fwd_keep_bytes(g);
         if (kb && c.keep_total + kb <= keepv_budget()) { keepV = (float*)c.alloc(kb); NEED(keepV); c.keep_total += kb; }
     }
+    const size_t ubytes = f16 ? 0 : conv_wino_u_bytes(g);          // fp32 Winograd layer: its filter transform is cached per update
+    if (ubytes && c.ucache_reserve(W.w, g.up ? 2 : 0, ubytes)) { set_error("workspace too small (filter-transform cache)"); return ACLGAN_ENOMEM; }
     const double es_in = in->dt ? 2.0 : 4.0, es_co = co->dt ? 2.0 : 4.0, es_out = out->dt ? 2.0 : 4.0, es_w = f16 ? 2.0 : 4.0;
     c.count(es_in * (double)in->numel() + es_w * (double)Co * g.K + 4.0 * Co + es_co * (double)co->numel());             // conv: x, w, bias -> y
     if (out != co) c.count((es_co + es_out) * (double)co->numel() + ((has_norm && residual) ? (residual->dt ? 2.0 : 4.0) * (double)co->numel() : 0.0));   // norm+act(+residual) / conversion: y -> out
     const size_t mark = c.top;
     // normalisation statistics from the conv epilogue where the forward kernel offers them (Winograd output transform)
-    const int schunk = (has_norm && !f16) ? conv_fwd_stats_chunk(g) : 0;
+    const int schunk = !has_norm ? 0 : (s_fwd ? conv_fwd16s_stats_chunk(g) : (!f16 ? conv_fwd_stats_chunk(g) : 0));
     float* stats = nullptr;
     if (schunk) { stats = c.allocf((size_t)2 * g.B * (HW / schunk) * Co); NEED(stats); }
     {
@@ -421,7 +446,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         void* fscr = nullptr;
         const size_t fb = s_fwd ? 0 : (f16 ? conv_fwd16_scratch_bytes(g) : conv_fwd_scratch_bytes(g));   // merged phase weights (upsample + 5x5 layers), split-K partials
         if (fb) { fscr = c.alloc(fb); NEED(fscr); }
-        if (s_fwd) RUN(conv_fwd16s(g, dt, in->d, W.w16, W.b, co->d, co->dt, c.st));
+        if (s_fwd) RUN(conv_fwd16s(g, dt, in->d, W.w16, W.b, co->d, co->dt, c.st, stats));
         else if (f16) RUN(conv_fwd16(g, dt, in->dt ? nullptr : in->d, W.w, W.w16, W.b, co->d, fscr, c.st, in->dt ? in->d : nullptr, co->dt));
         else RUN(conv_fwd(g, in->d, W.w, W.b, co->d, c.st, fscr, stats, keepV));
         c.top = fmark;
@@ -449,6 +474,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         if (train_w) c.count(es_in * (double)in->numel() + eg_co * (double)co->numel() + 4.0 * ((double)Co * g.K + Co));
         if (gin->need_grad) c.count(eg_co * (double)co->numel() + es_w * (double)Co * g.K + eg_in * (double)in->numel());
         const bool side = train_w && aclgan_ctx::side_enabled();      // this layer's weight gradient goes to the side stream
+        if (ubytes && gin->need_grad && !d16 && c.ucache_reserve(W.w, g.up ? 3 : 1, ubytes)) { set_error("workspace too small (filter-transform cache)"); return ACLGAN_ENOMEM; }
         float* g16 = nullptr;
         const size_t mark_pre = c.top;
         if (!has_norm && s_bwd && out->gdt == 0) {      // (with the side stream: kept below the closure's scratch mark -- that stream may read it later)
@@ -1183,7 +1209,10 @@ int aclgan_gen_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const
                       const aclgan_hparams* hp, float* losses, void* stream) {
     int rc = step_common(ctx, x_a, x_b, z, hp, losses, stream, 0);
     if (rc) return rc;
+    ctx->ucache_hook = WinoUCache{ctx, &aclgan_ctx::ucache_lookup};
+    set_wino_ucache(&ctx->ucache_hook);
     rc = gen_update_impl(*ctx, x_a, x_b, z, B, H, W, *hp, losses);
+    set_wino_ucache(nullptr);
     ctx->reset_step();
     return rc;
 }
@@ -1191,7 +1220,10 @@ int aclgan_dis_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const
                       const aclgan_hparams* hp, float* losses, void* stream) {
     int rc = step_common(ctx, x_a, x_b, z, hp, losses, stream, 1);
     if (rc) return rc;
+    ctx->ucache_hook = WinoUCache{ctx, &aclgan_ctx::ucache_lookup};
+    set_wino_ucache(&ctx->ucache_hook);
     rc = dis_update_impl(*ctx, x_a, x_b, z, B, H, W, *hp, losses);
+    set_wino_ucache(nullptr);
     ctx->reset_step();
     return rc;
 }

@@ -24,6 +24,8 @@ TDT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 @pytest.fixture(scope="module")
 def L():
     assert torch.cuda.is_available(), "these tests need the MI355X"
+    import os
+    os.environ.setdefault("ACLGAN_WGRAD16S_MINPIX", "64")      # exercise the pixel-major weight-gradient kernel at test sizes too
     import aclgan_amd  # noqa: F401
     from aclgan_amd import _lib
     return _lib
@@ -176,7 +178,7 @@ def test_conv_wgrad16_any_storage(L, case, dt, stx, stdy):
     xr32, dyr32 = xg.to(TDT[dt]).float(), (dyg.to(TDT[dt]).float() if stdy else dyg)
     L.check(L.lib.aclgan_conv2d_wgrad16_st(C.byref(d), code, L.ptr(xr32), 0, L.ptr(dyr32), 0, L.ptr(dw2), L.ptr(db2), L.ptr(scr), L.stream_ptr()))
     if stx and stdy and Ci % 128 == 0 and Co % 128 == 0 and not up:
-        assert _rel(dw, dw2) < 1e-5
+        assert _rel(dw, dw2) < 1e-5          # (bitwise below the pixel-count threshold of the LDS-DMA kernel, where the same kernel ran)
     else:
         assert torch.equal(dw, dw2)
     # reproducible bit for bit either way (ordered slices)
