@@ -110,6 +110,9 @@ SIGNATURES = {
     "aclgan_conv2d_wgrad16": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, vp, vp]),
     "aclgan_conv16s_ok": (ci, [C.POINTER(ConvDesc), ci]),
     "aclgan_conv2d_fwd16s": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp]),
+    "aclgan_set_tuning": (ci, [C.c_char_p, ci]),
+    "aclgan_conv2d_fwd16s_stats_chunk": (ci, [C.POINTER(ConvDesc)]),
+    "aclgan_conv2d_fwd16s_stats": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp, vp]),
     "aclgan_conv2d_dgrad16s_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_dgrad16s": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, ci, ci, vp, vp]),
     "aclgan_conv2d_wgrad16_st": (ci, [C.POINTER(ConvDesc), ci, vp, ci, vp, ci, vp, vp, vp, vp]),

@@ -1,4 +1,5 @@
 // api.hip -- error plumbing and the operator-level C ABI of libaclgan_hip (see include/aclgan_hip.h).
+#include <string.h>
 #include "common.h"
 
 #include <cstdarg>
@@ -211,6 +212,21 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
     rc = conv_fwd16s(g, dtype, x16, w16, bias, y, y_storage, (hipStream_t)stream);
     if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_fwd16s: no 16-bit-storage kernel for this shape (no upsample, Cin and Cout multiples of 64, grid >= 96 tiles)");
     return rc;
+}
+int aclgan_set_tuning(const char* key, int value) {
+    if (key && !strcmp(key, "glds_tile")) return set_glds_tile(value);
+    set_error("aclgan_set_tuning: unknown key");
+    return -1;
+}
+int aclgan_conv2d_fwd16s_stats_chunk(const aclgan_conv_desc* d) { ConvGeom g; return (d && make_geom(d, &g) == 0 && conv16_eligible(g, 0)) ? conv_fwd16s_stats_chunk(g) : 0; }
+int aclgan_conv2d_fwd16s_stats(const aclgan_conv_desc* d, int dtype, const void* x16, const void* w16, const float* bias, void* y, int y_storage,
+                               float* stats, void* stream) {
+    ConvGeom g;
+    int rc = make_geom(d, &g);
+    if (rc) return rc;
+    ACL_REQUIRE(y_storage == 0 || y_storage == dtype, "conv2d_fwd16s_stats: y storage must be fp32 or the compute dtype");
+    ACL_REQUIRE(stats, "conv2d_fwd16s_stats: null statistics buffer");
+    return conv_fwd16s(g, dtype, x16, w16, bias, y, y_storage, (hipStream_t)stream, stats);
 }
 size_t aclgan_conv2d_dgrad16s_scratch_bytes(const aclgan_conv_desc* d) { ConvGeom g; return make_geom(d, &g) ? 0 : conv_dgrad16s_scratch_bytes(g); }
 int aclgan_conv2d_dgrad16s(const aclgan_conv_desc* d, int dtype, const void* dy16, const void* w16t, void* dx, int dx_storage, int accumulate,

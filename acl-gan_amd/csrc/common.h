@@ -140,6 +140,7 @@ int conv_wgrad16(const ConvGeom& g, int dtype, const float* x, const float* dy, 
 bool conv16s_ok(const ConvGeom& g, int which);
 // stats (optional, conv_fwd16s_stats_chunk(g) > 0): [B][Ho*Wo / chunk][Co] (mean, M2) pairs of the STORED outputs -- norm_fwd's chunk partials
 int conv_fwd16s_stats_chunk(const ConvGeom& g);
+int set_glds_tile(int v);
 int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st, float* stats = nullptr);
 size_t conv_dgrad16s_scratch_bytes(const ConvGeom& g);
 // weight gradient with BOTH operands in the 16-bit dtype (Cin, Cout multiples of 128): pixel-major LDS-DMA tiles + transposing LDS reads

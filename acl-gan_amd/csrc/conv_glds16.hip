@@ -62,21 +62,25 @@ template <class T, int TM, int TN>
 __device__ __forceinline__ void mma_tile(const unsigned char* a, const unsigned char* b, int lane, f32x16 (&acc)[TM][TN]) {
     const int l31 = lane & 31, kh = lane >> 5;
     const int c0 = kh ^ ((l31 >> 1) & 7);            // chunk (2 ks + kh) ^ sw  =  (2 ks) ^ c0
-    u32x4 fa[TM][4], fb[TN][4];
+    constexpr int KG = TN >= 4 ? 2 : 4;              // k-steps whose fragments are in flight together (2 x 4 tiles: 96 fragment VGPRs would spill)
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int k0 = 0; k0 < 4; k0 += KG) {
+        u32x4 fa[TM][KG], fb[TN][KG];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(a + (t * 32 + l31) * ROWB + ((c0 ^ (2 * ks)) << 4));
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
+            for (int ks = 0; ks < KG; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(a + (t * 32 + l31) * ROWB + ((c0 ^ (2 * (k0 + ks))) << 4));
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(b + (t * 32 + l31) * ROWB + ((c0 ^ (2 * ks)) << 4));
+        for (int t = 0; t < TN; ++t)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < KG; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(b + (t * 32 + l31) * ROWB + ((c0 ^ (2 * (k0 + ks))) << 4));
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int ks = 0; ks < KG; ++ks)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
+    }
 }
 
 // store a wave's accumulators: element (row-index table ro[], column n) of a [rows][ld] matrix of storage `yst`.
@@ -86,8 +90,10 @@ template <int TM, int TN, class F>
 __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], const int* ro, int rbase, int nbase, int nmax, int ld, void* __restrict__ y,
                                           int yst, int lane, F&& fin) {
     const int l31 = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    // (compile-time column block j: a `#pragma unroll` j loop around a large `fin` is unrolled too late for the 2 x 4 tile, whose accumulator
+    //  array then stays in scratch through the whole main loop)
+    auto col = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
         const int n = nbase + j * 32 + l31;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -113,7 +119,10 @@ __device__ __forceinline__ void store_acc(const f32x16 (&acc)[TM][TN], const int
                 }
             }
         }
-    }
+    };
+    col(std::integral_constant<int, 0>{});
+    if constexpr (TN > 1) col(std::integral_constant<int, 1>{});
+    if constexpr (TN > 2) { col(std::integral_constant<int, 2>{}); col(std::integral_constant<int, 3>{}); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -125,34 +134,36 @@ struct FwdSP {
     float2* stats;     // optional: per (128-row tile, channel) (mean, M2) of the stored outputs -- the normalisation layer's chunk partials
 };
 
-// NBUF = 2: two LDS buffers, one barrier per k-tile, 2 workgroups per CU (the DMA of tile t+1 flies under tile t's MFMAs of the same
-// workgroup).  NBUF = 1: one buffer, two barriers per k-tile, half the LDS -> 4 workgroups per CU: the other three workgroups' MFMAs
-// cover a workgroup's DMA issue + flight (an LDS-DMA issue costs its wave ~100-180 cycles, eight per k-tile against 512 MFMA cycles).
-template <class T, int BN, int NBUF>
-__global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(FwdSP p) {
+// Tile geometry (template): WM x WN waves, each 64 rows x (TN * 32) columns -> BM = 64 WM, BN = 32 TN WN; k-tile 64.
+//   <2,2,2> 128 x 128 (4 waves, 2 workgroups per CU)   <2,2,1> 128 x 64   <4,2,2> 256 x 128 (8 waves, 1 per CU)   <4,2,4> 256 x 256
+// Operand bytes per MFMA: 512 at 128 x 128, 384 at 256 x 128, 256 at 256 x 256 -- and yet the 128-row tiles win in the step (see glds_tile).
+// NBUF = 2: two LDS buffers, one barrier per k-tile (the DMA of tile t+1 flies under tile t's MFMAs).  NBUF = 1 (128-row tiles only, experiments):
+// one buffer, two barriers per k-tile, 4 workgroups per CU.
+template <class T, int WM, int WN, int TN, int NBUF>
+__global__ void __launch_bounds__(WM * WN * 64, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(FwdSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (device pass only: the host pass cannot instantiate a template body that declares __amdgpu_buffer_rsrc_t locals -- its launch stub would stay undefined)
-
-    constexpr int BM = 128, TM = 2, TN = BN / 64, B_IT = BN / 32;
+    constexpr int TM = 2, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;       // 1 KB DMA pieces (8 rows) per wave and k-tile
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * (A_BYTES + B_BYTES) + BM * 4];
     int* ro = reinterpret_cast<int*>(smem + NBUF * (A_BYTES + B_BYTES));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_map(blockIdx.x, p.nwg);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int hw = p.Ho * p.Wo;
 
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         ro[r] = m < p.M ? m : -1;                 // output pixel index == GEMM row (NHWC, no phases / rings here)
     }
-    // DMA rows of this lane: A rows 32 wave + 8 n + (lane >> 3), n = 0..3; the lane copies chunk (lane & 7) ^ swz(row) of its rows
+    // DMA rows of this lane: A rows (BM / NW) wave + 8 n + (lane >> 3); the lane copies chunk (lane & 7) ^ swz(row) of its rows
     const int lr = lane >> 3, lj = lane & 7;
-    int ay[4], ax[4], ab[4], acs[4];
+    int ay[A_IT], ax[A_IT], ab[A_IT], acs[A_IT];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int row = 32 * wave + 8 * n + lr;
+    for (int n = 0; n < A_IT; ++n) {
+        const int row = (BM / NW) * wave + 8 * n + lr;
         const int m = min(m0 + row, p.M - 1);     // past the end: any valid row (never stored)
         const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
         ay[n] = oy * p.s - p.p; ax[n] = ox * p.s - p.p; ab[n] = b * p.Hi * p.Wi;
@@ -161,40 +172,33 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(Fwd
     int bvo[B_IT];
 #pragma unroll
     for (int n = 0; n < B_IT; ++n) {
-        const int row = (BN / 4) * wave + 8 * n + lr;
+        const int row = (BN / NW) * wave + 8 * n + lr;
         bvo[n] = (min(n0 + row, p.Co - 1) * p.K + (lj ^ ((row >> 1) & 7)) * 8) * 2;
     }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x16, (long long)p.B * p.Hi * p.Wi * p.Ci * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16, (long long)p.Co * p.K * 2);
     const int cpt = p.Ci >> 6;                     // k-tiles per filter tap
     const int nk = p.K >> 6;
-    int avo[4];
+    int avo[A_IT];
     int f_tap = -1;
 
-    int soff_a = 0, soff_b = 0;
-    auto setup = [&](int kt) __attribute__((always_inline)) {      // gather offsets of k-tile kt (block-uniform branch at a new filter tap)
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
         const int tap = kt / cpt, cc = kt - tap * cpt;
-        if (tap != f_tap) {
+        if (tap != f_tap) {                        // block-uniform: new filter tap -> redo the gather offsets
             f_tap = tap;
             const int ky = tap / p.k, kx = tap - ky * p.k;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < A_IT; ++n) {
                 const int iy = refl(ay[n] + ky, p.Hi), ix = refl(ax[n] + kx, p.Wi);
                 avo[n] = ((ab[n] + iy * p.Wi + ix) * p.Ci + acs[n]) * 2;
             }
         }
-        soff_a = cc * 128; soff_b = kt * 128;
-    };
-    auto piece = [&](int n, int buf) __attribute__((always_inline)) {   // DMA piece n of the A tile and (n < B_IT) of the B tile into buffer buf
-        unsigned char* da = smem + buf * A_BYTES + (32 * wave) * ROWB;
-        unsigned char* db = smem + NBUF * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], soff_a, 0, 0);
-        if (n < B_IT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n < B_IT ? n : 0], soff_b, 0, 0);
-    };
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        setup(kt);
+        unsigned char* da = smem + buf * A_BYTES + ((BM / NW) * wave) * ROWB;
+        unsigned char* db = smem + NBUF * A_BYTES + buf * B_BYTES + ((BN / NW) * wave) * ROWB;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) piece(n, buf);
+        for (int n = 0; n < A_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
+#pragma unroll
+        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], kt * 128, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -211,13 +215,13 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(Fwd
             const int cur = kt & 1;
             __syncthreads();                       // (vmcnt(0) +) barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
             if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-            mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+            mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
         }
     } else {
         for (int kt = 0; kt < nk; ++kt) {
             issue(kt, 0);
             __syncthreads();                       // tile kt has landed
-            mma_tile<T, TM, TN>(smem + (wm * 64) * ROWB, smem + A_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+            mma_tile<T, TM, TN>(smem + (wm * 64) * ROWB, smem + A_BYTES + (wn * TN * 32) * ROWB, lane, acc);
             __syncthreads();                       // every wave is done reading: the buffer may be refilled
         }
     }
@@ -225,16 +229,17 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(Fwd
     const float* bias = p.bias;
     const int act = p.act;
     if (p.stats) {
-        // Normalisation statistics from the epilogue (block-uniform; the launcher offers it only when every tile is 128 full rows of one
-        // sample): (mean, M2) of the 128 STORED outputs of each channel of this tile = one chunk partial of norm_finalize_*.  A lane holds
-        // 2 x 16 rows of each of its TN columns; lanes l / l ^ 32 and the two row-halves of the workgroup (waves wm = 0 / 1) are merged
-        // with Chan's formula for equal counts.
+        // Normalisation statistics from the epilogue (block-uniform; the launcher offers it only when every tile is BM full rows of one
+        // sample): (mean, M2) of the BM STORED outputs of each channel of this tile = one chunk partial of norm_finalize_*.  A lane holds
+        // 2 x 16 rows of each of its TN columns; lanes l / l ^ 32, then the WM row blocks of the workgroup, are merged with Chan's formula.
         const int l31 = lane & 31, lh = lane >> 5;
         float2* red = reinterpret_cast<float2*>(smem);
         __syncthreads();                           // every wave is done with the operand buffers
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        // (one column block per call with a COMPILE-TIME j: as a `#pragma unroll` loop over j the 2 x 4 tile's body is unrolled too late
+        //  for the accumulator array to be split into registers again -- it then lives in scratch through the whole main loop)
+        auto col = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int n = n0 + wn * TN * 32 + j * 32 + l31;
             const float bv = (bias && n < p.Co) ? bias[n] : 0.f;
             float sum = 0.f;
 #pragma unroll
@@ -255,37 +260,68 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(Fwd
             const float dm = om - mean;
             q = q + oq + dm * dm * 16.f;           // n_a n_b / (n_a + n_b) = 32 * 32 / 64
             mean = 0.5f * (mean + om);
-            if (lh == 0) red[wm * BN + wn * (BN / 2) + j * 32 + l31] = make_float2(mean, q);
-        }
+            if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + l31] = make_float2(mean, q);
+        };
+        col(std::integral_constant<int, 0>{});
+        if constexpr (TN > 1) col(std::integral_constant<int, 1>{});
+        if constexpr (TN > 2) { col(std::integral_constant<int, 2>{}); col(std::integral_constant<int, 3>{}); }
         __syncthreads();
         if (tid < BN && n0 + tid < p.Co) {
-            const float2 a = red[tid], b2 = red[BN + tid];
-            const float dm = b2.x - a.x;
-            p.stats[(size_t)(m0 / BM) * p.Co + n0 + tid] = make_float2(0.5f * (a.x + b2.x), a.y + b2.y + dm * dm * 32.f);
+            float cnt = 64.f, mean = red[tid].x, m2 = red[tid].y;
+#pragma unroll
+            for (int i = 1; i < WM; ++i) {
+                const float2 o = red[i * BN + tid];
+                const float dm = o.x - mean, tot = cnt + 64.f;
+                mean += dm * (64.f / tot);
+                m2 += o.y + dm * dm * (cnt * 64.f / tot);
+                cnt = tot;
+            }
+            p.stats[(size_t)(m0 / BM) * p.Co + n0 + tid] = make_float2(mean, m2);
         }
-        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Co, p.Co, p.y, p.yst, lane, [](float v, int) { return v; });
+        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Co, p.Co, p.y, p.yst, lane, [](float v, int) { return v; });
     } else {
-        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Co, p.Co, p.y, p.yst, lane,
+        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Co, p.Co, p.y, p.yst, lane,
                           [&](float v, int n) { return act_apply(v + (bias ? bias[n] : 0.f), act); });
     }
 #endif
 }
 
+// tile choice.  Measured inside the step (profiles/r03_experiments.md, same box back to back) the 8-wave tiles LOSE although they move fewer
+// operand bytes per MFMA: bf16 B=8 56.3 ms with 128-row tiles against 60.4 with "largest tile that fills the chip", fp16 B=32 182.4 against
+// 186.7 -- one 8-wave workgroup per CU has nothing to run while it waits at its barrier, two 4-wave workgroups cover each other.  So:
+// 128-row tiles by default; ACLGAN_GLDS_TILE = 2 / 3 forces 256 x 128 / 256 x 256 where the shape allows, 4 = the largest-tile rule
+// (kept tested: tests/test_gpu_ops16s.py runs every tile).  Returns 1 / 2 / 3.
+int g_tile_force = -1;
+int glds_tile(int rows, int N) {
+    int& force = g_tile_force;
+    if (force < 0) { const char* e = getenv("ACLGAN_GLDS_TILE"); force = e ? atoi(e) : 0; }
+    const int t256 = N % 256 == 0 ? cdiv(rows, 256) * (N / 256) : 0, t128 = N % 128 == 0 ? cdiv(rows, 256) * (N / 128) : 0;
+    if (force == 3 && t256) return 3;
+    if (force == 2 && t128) return 2;
+    if (force == 4) return t256 >= 224 ? 3 : t128 >= 224 ? 2 : 1;      // "largest tile that fills the chip"
+    return 1;
+}
+
 template <class T>
 int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
-    const int BN = g.Co % 128 == 0 ? 128 : 64;
-    p.tiles_n = g.Co / BN;
-    p.nwg = cdiv(g.M, 128) * p.tiles_n;
-    // buffers: one (4 workgroups per CU) once the grid fills those 1024 slots to 3/4, else two (2 per CU, DMA under the workgroup's own
-    // MFMAs).  Measured (profiles/r03_experiments.md): ResBlock shape B=8 (512 tiles) 53 us vs 58 us, B=32 (2048) 200 vs 173 us, first
-    // wide discriminator layer (768 tiles) 60 vs 46 us.  ACLGAN_GLDS_NBUF=1|2 forces one.
+    const int tc = glds_tile(g.M, g.Co);
     static int force = -1;
     if (force < 0) { const char* e = getenv("ACLGAN_GLDS_NBUF"); force = e ? atoi(e) : 0; }
-    const int nbuf = force == 1 ? 1 : (force == 2 ? 2 : (p.nwg >= 768 ? 1 : 2));
-    if (BN == 128 && nbuf == 2) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128, 2>), dim3(p.nwg), dim3(256), 0, st, p);
-    else if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 128, 1>), dim3(p.nwg), dim3(256), 0, st, p);
-    else if (nbuf == 2) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 64, 2>), dim3(p.nwg), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 64, 1>), dim3(p.nwg), dim3(256), 0, st, p);
+    if (tc == 3) {
+        p.tiles_n = g.Co / 256; p.nwg = cdiv(g.M, 256) * p.tiles_n;
+        hipLaunchKernelGGL((conv_fwd16s_kernel<T, 4, 2, 4, 2>), dim3(p.nwg), dim3(512), 0, st, p);
+    } else if (tc == 2) {
+        p.tiles_n = g.Co / 128; p.nwg = cdiv(g.M, 256) * p.tiles_n;
+        hipLaunchKernelGGL((conv_fwd16s_kernel<T, 4, 2, 2, 2>), dim3(p.nwg), dim3(512), 0, st, p);
+    } else {
+        const int BN = g.Co % 128 == 0 ? 128 : 64;
+        p.tiles_n = g.Co / BN; p.nwg = cdiv(g.M, 128) * p.tiles_n;
+        // (the single-buffer variant, 4 workgroups per CU, wins on ISOLATED large grids -- B=32 ResBlock shape 173 vs 200 us -- but loses
+        //  badly inside the step: fp16 B=32 step 237.6 vs 185.0 ms, profiles/r03_experiments.md; ACLGAN_GLDS_NBUF=1 selects it)
+        if (BN == 128 && force != 1) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 2, 2>), dim3(p.nwg), dim3(256), 0, st, p);
+        else if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 2, 1>), dim3(p.nwg), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 1, 2>), dim3(p.nwg), dim3(256), 0, st, p);
+    }
     ACL_CHECK_LAUNCH("conv_fwd16s_kernel");
     return ACLGAN_OK;
 }
@@ -298,24 +334,24 @@ struct DgSP {
     int B, Ho, Wo, Co, Ci, k, s, Hp, Wp, Hc, Wc, Mc, tiles_n, nwg, pst;
 };
 
-template <class T, int BN>
-__global__ void __launch_bounds__(256, 2) conv_dgrad16s_kernel(DgSP p) {
-#if defined(__HIP_DEVICE_COMPILE__)   // (device pass only: the host pass cannot instantiate a template body that declares __amdgpu_buffer_rsrc_t locals -- its launch stub would stay undefined)
-
-    constexpr int BM = 128, TM = 2, TN = BN / 64, B_IT = BN / 32;
+template <class T, int WM, int WN, int TN>
+__global__ void __launch_bounds__(WM * WN * 64, 2) conv_dgrad16s_kernel(DgSP p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (device pass only, see conv_fwd16s_kernel)
+    constexpr int TM = 2, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES) + BM * 4];
     int* ro = reinterpret_cast<int*>(smem + 2 * (A_BYTES + B_BYTES));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_map(blockIdx.x, p.nwg);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int cls = blockIdx.z, cy = cls / p.s, cx = cls - cy * p.s;
     const int Tx = (p.k - cx + p.s - 1) / p.s, Ty = (p.k - cy + p.s - 1) / p.s;
     const int hwc = p.Hc * p.Wc;
 
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         int oo = -1;
         if (m < p.Mc) {
@@ -326,10 +362,10 @@ __global__ void __launch_bounds__(256, 2) conv_dgrad16s_kernel(DgSP p) {
         ro[r] = oo;
     }
     const int lr = lane >> 3, lj = lane & 7;
-    int ay[4], ax[4], ab[4], acs[4];
+    int ay[A_IT], ax[A_IT], ab[A_IT], acs[A_IT];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int row = 32 * wave + 8 * n + lr;
+    for (int n = 0; n < A_IT; ++n) {
+        const int row = (BM / NW) * wave + 8 * n + lr;
         const int m = m0 + row;
         if (m < p.Mc) {
             const int b = m / hwc, rem = m - b * hwc, y2 = rem / p.Wc;
@@ -341,42 +377,35 @@ __global__ void __launch_bounds__(256, 2) conv_dgrad16s_kernel(DgSP p) {
     int bvo[B_IT];
 #pragma unroll
     for (int n = 0; n < B_IT; ++n) {
-        const int row = (BN / 4) * wave + 8 * n + lr;
+        const int row = (BN / NW) * wave + 8 * n + lr;
         bvo[n] = (min(n0 + row, p.Ci - 1) * p.Co + (lj ^ ((row >> 1) & 7)) * 8) * 2;
     }
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy16, (long long)p.B * p.Ho * p.Wo * p.Co * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16t, (long long)p.k * p.k * p.Ci * p.Co * 2);
     const int cpt = p.Co >> 6;
     const int nk = Ty * Tx * cpt;
-    int avo[4];
+    int avo[A_IT];
     int f_tap = -1, tapoff = 0;
 
-    int soff_a = 0, soff_b = 0;
-    auto setup = [&](int kt) __attribute__((always_inline)) {
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
         const int t = kt / cpt, cc = kt - t * cpt;
         if (t != f_tap) {
             f_tap = t;
             const int ty = t / Tx, tx = t - ty * Tx;
             tapoff = ((cy + p.s * ty) * p.k + (cx + p.s * tx)) * p.Ci * p.Co * 2;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < A_IT; ++n) {
                 const int oy = ay[n] - ty, ox = ax[n] - tx;
                 const bool ok = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
                 avo[n] = ok ? (((ab[n] * p.Ho + oy) * p.Wo + ox) * p.Co + acs[n]) * 2 : OOB;
             }
         }
-        soff_a = cc * 128; soff_b = tapoff + cc * 128;
-    };
-    auto piece = [&](int n, int buf) __attribute__((always_inline)) {
-        unsigned char* da = smem + buf * A_BYTES + (32 * wave) * ROWB;
-        unsigned char* db = smem + 2 * A_BYTES + buf * B_BYTES + ((BN / 4) * wave) * ROWB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], soff_a, 0, 0);
-        if (n < B_IT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n < B_IT ? n : 0], soff_b, 0, 0);
-    };
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        setup(kt);
+        unsigned char* da = smem + buf * A_BYTES + ((BM / NW) * wave) * ROWB;
+        unsigned char* db = smem + 2 * A_BYTES + buf * B_BYTES + ((BN / NW) * wave) * ROWB;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) piece(n, buf);
+        for (int n = 0; n < A_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
+#pragma unroll
+        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], tapoff + cc * 128, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -392,19 +421,29 @@ __global__ void __launch_bounds__(256, 2) conv_dgrad16s_kernel(DgSP p) {
         const int cur = kt & 1;
         __syncthreads();
         if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-        mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + 2 * A_BYTES + cur * B_BYTES + (wn * (BN / 2)) * ROWB, lane, acc);
+        mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + 2 * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
     }
-    store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * (BN / 2), p.Ci, p.Ci, p.dxp, p.pst, lane, [](float v, int) { return v; });
+    store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Ci, p.Ci, p.dxp, p.pst, lane, [](float v, int) { return v; });
 #endif
 }
 
 template <class T>
 int launch_dgrad16s(const ConvGeom& g, DgSP p, hipStream_t st) {
-    const int BN = g.Ci % 128 == 0 ? 128 : 64;
-    p.tiles_n = g.Ci / BN;
-    p.nwg = cdiv(p.Mc, 128) * p.tiles_n;
-    if (BN == 128) hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 128>), dim3(p.nwg, 1, g.s * g.s), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 64>), dim3(p.nwg, 1, g.s * g.s), dim3(256), 0, st, p);
+    const int tc = glds_tile(p.Mc * g.s * g.s, g.Ci);      // (rows of all stride-parity classes together fill the chip)
+    const dim3 z(1, 1, g.s * g.s);
+    if (tc == 3) {
+        p.tiles_n = g.Ci / 256; p.nwg = cdiv(p.Mc, 256) * p.tiles_n;
+        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 4, 2, 4>), dim3(p.nwg, 1, z.z), dim3(512), 0, st, p);
+    } else if (tc == 2) {
+        p.tiles_n = g.Ci / 128; p.nwg = cdiv(p.Mc, 256) * p.tiles_n;
+        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 4, 2, 2>), dim3(p.nwg, 1, z.z), dim3(512), 0, st, p);
+    } else if (g.Ci % 128 == 0) {
+        p.tiles_n = g.Ci / 128; p.nwg = cdiv(p.Mc, 128) * p.tiles_n;
+        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 2>), dim3(p.nwg, 1, z.z), dim3(256), 0, st, p);
+    } else {
+        p.tiles_n = g.Ci / 64; p.nwg = cdiv(p.Mc, 128) * p.tiles_n;
+        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 1>), dim3(p.nwg, 1, z.z), dim3(256), 0, st, p);
+    }
     ACL_CHECK_LAUNCH("conv_dgrad16s_kernel");
     return ACLGAN_OK;
 }
@@ -647,11 +686,19 @@ bool enabled() {
 // ------------------------------------------------------------------------------------------
 // which: 0 forward, 1 dgrad.  The forward also wants a grid that fills the chip without split-K (small late-discriminator maps keep the
 // split-K kernel of conv_fast16.hip, which reads the same 16-bit activations through its A16 path).
+// tuning / test knob behind aclgan_set_tuning("glds_tile", v): same values as ACLGAN_GLDS_TILE; returns the previous value
+int set_glds_tile(int v) {
+    if (g_tile_force < 0) glds_tile(1, 1);
+    const int old = g_tile_force;
+    g_tile_force = v < 0 ? 0 : v;
+    return old;
+}
+
 bool conv16s_ok(const ConvGeom& g, int which) {
     if (!enabled() || !shape_ok(g)) return false;
     if (which == 0) {
         const int BN = g.Co % 128 == 0 ? 128 : 64;
-        return cdiv(g.M, 128) * (g.Co / BN) >= 96 || g.K <= 1024;
+        return cdiv(g.M, 128) * (g.Co / BN) >= 96 || g.K <= 1024;      // (a grid that fills the chip without split-K)
     }
     return true;
 }
@@ -660,7 +707,9 @@ bool conv16s_ok(const ConvGeom& g, int which) {
 int conv_fwd16s_stats_chunk(const ConvGeom& g) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("ACLGAN_NOSTATFUSE"); off = (e && atoi(e)) ? 1 : 0; }
-    return (!off && conv16s_ok(g, 0) && (g.Ho * g.Wo) % 128 == 0) ? 128 : 0;
+    if (off || !conv16s_ok(g, 0)) return 0;
+    const int rows = glds_tile(g.M, g.Co) >= 2 ? 256 : 128;      // the statistics chunk is the launch's row tile
+    return (g.Ho * g.Wo) % rows == 0 ? rows : 0;
 }
 
 int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st, float* stats) {

@@ -280,6 +280,18 @@ int aclgan_conv2d_wgrad16(const aclgan_conv_desc* d, int dtype, const float* x, 
 int aclgan_conv16s_ok(const aclgan_conv_desc* d, int which);
 /* forward on 16-bit x (NHWC) and the OHWI weight pack: y (storage y_storage) = act(conv(x16) + bias) */
 int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, const void* w16, const float* bias, void* y, int y_storage, void* stream);
+/* Process-wide tuning knobs that also exist as environment variables, settable at run time (tests use this to run every tile shape of
+ * csrc/conv_glds16.hip).  key "glds_tile": 0 / 1 = 128-row tiles (default), 2 = 256 x 128, 3 = 256 x 256 where the shape allows, 4 = the
+ * largest tile that still fills the chip.  Returns the previous value, -1 for an unknown key.  Not thread-safe against running launches. */
+int aclgan_set_tuning(const char* key, int value);
+/* The same launch with the normalisation statistics taken from its epilogue (round 3; replaces the norm_stats pass over y that
+ * follows the conv in reference networks.py:382-395 Conv2dBlock.forward -> self.norm).  aclgan_conv2d_fwd16s_stats_chunk = rows R per
+ * statistics chunk (the launch's row tile: 128 or 256; 0 = not offered: Ho * Wo must be a multiple of R).  stats receives
+ * [B * Ho * Wo / R][Cout] float2 (mean, M2 = sum of squared deviations) of the STORED outputs of each chunk, chunk c = rows c R .. c R + R - 1
+ * of the [B * Ho * Wo][Cout] output. */
+int aclgan_conv2d_fwd16s_stats_chunk(const aclgan_conv_desc* d);
+int aclgan_conv2d_fwd16s_stats(const aclgan_conv_desc* d, int dtype, const void* x16, const void* w16, const float* bias, void* y, int y_storage,
+                               float* stats, void* stream);
 /* dgrad on 16-bit dy and the transposed weight pack: dx (storage dx_storage) (+)= ...; ONE launch over the padded grid into `scratch`
  * + an ordered fold of the reflection: no atomics, bit-reproducible */
 size_t aclgan_conv2d_dgrad16s_scratch_bytes(const aclgan_conv_desc* d);

@@ -31,6 +31,16 @@ def L():
     return _lib
 
 
+@pytest.fixture(params=[1, 4], ids=["tile128", "tilemax"])
+def tile(request, L):
+    """1 = the default 128-row tiles; 4 = the largest tile that still fills the chip (256 x 128 / 256 x 256 eight-wave workgroups:
+    measured slower inside the step, kept as a tested option -- profiles/r03_experiments.md)"""
+    old = L.lib.aclgan_set_tuning(b"glds_tile", request.param)
+    assert old >= 0
+    yield request.param
+    L.lib.aclgan_set_tuning(b"glds_tile", old)
+
+
 # (B, Hi, Wi, Ci, Co, k, s, p, act)
 CASES = [
     (2, 64, 64, 256, 256, 3, 1, 1, "none"),     # ResBlock conv: 64 x 2 tiles of 128 x 128, 36 k-tiles over 9 taps
@@ -39,6 +49,12 @@ CASES = [
     (2, 16, 16, 256, 512, 4, 2, 1, "lrelu"),    # late discriminator conv (small map, K = 4096): forward keeps the split-K kernel, dgrad runs here
     (2, 12, 12, 128, 128, 1, 1, 0, "none"),     # 1x1, no padding
     (1, 9, 7, 64, 64, 3, 1, 1, "none"),         # a single ragged tile
+    # grids large enough for the 8-wave tiles (csrc/conv_glds16.hip glds_tile: the largest tile with >= 224 workgroups)
+    (7, 64, 64, 64, 256, 3, 1, 1, "relu"),      # forward: 112 x 2 tiles of 256 x 128
+    (14, 64, 64, 64, 256, 3, 1, 1, "lrelu"),    # forward: 224 tiles of 256 x 256
+    (7, 62, 66, 256, 64, 3, 1, 1, "none"),      # dgrad: N = Cin = 256 -> 256 x 128 tiles over the padded grid, ragged last tile
+    (15, 62, 62, 256, 64, 3, 1, 1, "none"),     # dgrad: 256 x 256 tiles
+    (8, 64, 64, 128, 256, 4, 2, 1, "none"),     # stride 2 with big tiles on the dgrad side (four parity classes of the padded grid)
 ]
 
 
@@ -81,7 +97,7 @@ def test_cast_storage_round_trip(L, dt):
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_fwd16s(L, case, dt):
+def test_conv_fwd16s(L, case, dt, tile):
     from gpu_util import conv_desc, out_hw, nhwc, nchw, ohwi
     B, Hi, Wi, Ci, Co, k, s, p, act = case
     d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, 0, act)
@@ -112,8 +128,45 @@ def test_conv_fwd16s(L, case, dt):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("yst", [0, 1])
+@pytest.mark.parametrize("case", [CASES[0], (4, 32, 32, 64, 64, 3, 1, 1, "none"), CASES[6], CASES[7], (16, 32, 32, 64, 128, 3, 1, 1, "relu")])
+def test_conv_fwd16s_epilogue_statistics(L, case, dt, yst, tile):
+    """The (mean, M2) chunk partials the forward launch emits for the normalisation layer == the statistics of the outputs AS STORED
+    (rounded when y is 16-bit), chunk = the launch's row tile (128 / 256 rows)."""
+    from gpu_util import conv_desc, out_hw, nhwc, ohwi
+    B, Hi, Wi, Ci, Co, k, s, p, act = case
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, 0, act)
+    R = L.lib.aclgan_conv2d_fwd16s_stats_chunk(C.byref(d))
+    assert R in (128, 256), "every case here is a shape the step fuses the statistics for"
+    if case in (CASES[6], CASES[7]): assert R == (256 if tile == 4 else 128)
+    x, w, b = _t(case, 2)
+    wg, bg = ohwi(w).cuda(), b.cuda()
+    x16 = nhwc(x).cuda().to(TDT[dt])
+    w16, _ = _packs(L, wg, dt)
+    Ho, Wo = out_hw(Hi, Wi, k, s, p, 0)
+    code = L.DTYPE[dt]
+    st = code if yst else 0
+    M = B * Ho * Wo
+    y = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda").to(TDT[dt] if yst else torch.float32)
+    stats = torch.full((M // R, Co, 2), float("nan"), device="cuda")
+    L.check(L.lib.aclgan_conv2d_fwd16s_stats(C.byref(d), code, L.ptr(x16), L.ptr(w16), L.ptr(bg), L.ptr(y), st, L.ptr(stats), L.stream_ptr()), "fwd16s_stats")
+    y_plain = torch.empty_like(y)
+    L.check(L.lib.aclgan_conv2d_fwd16s(C.byref(d), code, L.ptr(x16), L.ptr(w16), L.ptr(bg), L.ptr(y_plain), st, L.stream_ptr()), "fwd16s")
+    assert torch.equal(y, y_plain)                       # the statistics do not change what is stored
+    yc = y.double().reshape(M // R, R, Co)
+    mean = yc.mean(1)
+    m2 = ((yc - mean[:, None]) ** 2).sum(1)
+    sd = yc.std().item()
+    assert (stats[..., 0].double() - mean).abs().max().item() < 1e-5 * max(sd, 1e-3)
+    assert ((stats[..., 1].double() - m2).abs() / m2.clamp_min(1e-6 * R * sd * sd)).max().item() < 1e-4
+    s2 = torch.empty_like(stats)
+    L.check(L.lib.aclgan_conv2d_fwd16s_stats(C.byref(d), code, L.ptr(x16), L.ptr(w16), L.ptr(bg), L.ptr(y), st, L.ptr(s2), L.stream_ptr()))
+    assert torch.equal(stats, s2)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_dgrad16s(L, case, dt):
+def test_conv_dgrad16s(L, case, dt, tile):
     from gpu_util import conv_desc, nhwc, nchw, ohwi
     B, Hi, Wi, Ci, Co, k, s, p, act = case
     d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, 0, "none")
