@@ -71,6 +71,8 @@ SIGNATURES = {
     "aclgan_version": (ci, []),
     "aclgan_launch_count": (C.c_longlong, []),
     "aclgan_gemm_slices_f32": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "aclgan_gemm_slices_x3_scratch_bytes": (sz, [ci, ci, ci, ci]),
+    "aclgan_gemm_slices_x3": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "aclgan_set_deterministic": (ci, [ci]),
     "aclgan_get_deterministic": (ci, []),
     "aclgan_last_error": (C.c_char_p, []),

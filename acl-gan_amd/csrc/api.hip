@@ -45,6 +45,24 @@ long long aclgan_launch_count(void) { return g_launches; }
 const char* aclgan_last_error(void) { return g_err; }
 
 // the batched-GEMM launch of the Winograd pipeline alone (the step's dominant kernel): measurement / test support
+size_t aclgan_gemm_slices_x3_scratch_bytes(int T, int K, int N, int nslices) {
+    return (size_t)3 * 2 * ((size_t)nslices * T * K + (size_t)nslices * N * K) + 512;
+}
+int aclgan_gemm_slices_x3(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, void* scratch, void* stream) {
+    ACL_REQUIRE(Cm && scratch && T > 0 && K > 0 && N > 0 && nslices > 0 && ((A && Bm) || (!A && !Bm)), "gemm_slices_x3: bad argument");
+    if (!gemm_x3_shape_ok(T, K, N)) { set_error("gemm_slices_x3: K must be a multiple of 32 and N of 64"); return ACLGAN_EUNSUPPORTED; }
+    const int64_t na = (int64_t)nslices * T * K, nb = (int64_t)nslices * N * K;
+    char* a3 = (char*)scratch;
+    char* b3 = a3 + (((size_t)6 * na + 255) & ~(size_t)255);
+    int rc = ACLGAN_OK;
+    if (A) {          // (A == B == NULL: the planes of an earlier call are still in scratch -- bench.py times the GEMM launch alone that way)
+        rc = split3_planes(A, a3, na, na, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = split3_planes(Bm, b3, nb, nb, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return gemm_slices_x3(a3, (size_t)na * 2, b3, (size_t)nb * 2, Cm, T, K, N, nslices, 0, (hipStream_t)stream);
+}
 int aclgan_gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, int N, int nslices, void* stream) {
     ACL_REQUIRE(A && Bm && Cm && nslices >= 1, "null argument");
     return gemm_slices_f32(A, Bm, Cm, T, K, N, nslices, 0, (hipStream_t)stream);
@@ -215,6 +233,7 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
 }
 int aclgan_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "glds_tile")) return set_glds_tile(value);
+    if (key && !strcmp(key, "wino_x3")) return set_wino_x3(value);
     set_error("aclgan_set_tuning: unknown key");
     return -1;
 }

@@ -141,6 +141,11 @@ bool conv16s_ok(const ConvGeom& g, int which);
 // stats (optional, conv_fwd16s_stats_chunk(g) > 0): [B][Ho*Wo / chunk][Co] (mean, M2) pairs of the STORED outputs -- norm_fwd's chunk partials
 int conv_fwd16s_stats_chunk(const ConvGeom& g);
 int set_glds_tile(int v);
+int set_wino_x3(int v);
+// gemm_bf16x3.hip: fp32-accurate GEMM slices on the bf16 matrix cores from 3-plane (h, m, l) bf16 operands
+bool gemm_x3_shape_ok(int T, int K, int N);
+int gemm_slices_x3(const void* A3, size_t a_plane, const void* B3, size_t b_plane, float* C, int T, int K, int N, int nslices, int a_mod, hipStream_t st);
+int split3_planes(const float* x, void* out, int64_t n, int64_t plane_elems, hipStream_t st);
 int conv_fwd16s(const ConvGeom& g, int dtype, const void* x16, const void* w16, const float* bias, void* y, int yst, hipStream_t st, float* stats = nullptr);
 size_t conv_dgrad16s_scratch_bytes(const ConvGeom& g);
 // weight gradient with BOTH operands in the 16-bit dtype (Cin, Cout multiples of 128): pixel-major LDS-DMA tiles + transposing LDS reads

@@ -139,16 +139,30 @@ struct FwdSP {
 // Operand bytes per MFMA: 512 at 128 x 128, 384 at 256 x 128, 256 at 256 x 256 -- and yet the 128-row tiles win in the step (see glds_tile).
 // NBUF = 2: two LDS buffers, one barrier per k-tile (the DMA of tile t+1 flies under tile t's MFMAs).  NBUF = 1 (128-row tiles only, experiments):
 // one buffer, two barriers per k-tile, 4 workgroups per CU.
-template <class T, int WM, int WN, int TN, int NBUF>
-__global__ void __launch_bounds__(WM * WN * 64, NBUF == 1 ? 4 : 2) conv_fwd16s_kernel(FwdSP p) {
+// Wave specialisation (NP > 0; round 3, scripts/microbench/lds_dma_rate.hip): a wave that issues LDS-DMA loads is held at ISSUE while the CU's
+// vector-memory queue is full -- in program order its MFMAs then wait behind its own copies, and copy time and multiply time ADD UP
+// (microbenchmark, 4 waves x 12 KB + 48 MFMAs per stage: 0.69 us copies alone, 0.91 us MFMAs alone, 1.32 us together; only a second
+// workgroup on the CU hides part of it).  With NP producer waves that do nothing but copy and WM x WN consumer waves that do nothing but
+// multiply the same stage takes 0.98 us (= the slower of the two).  Producers run S - 1 k-tiles ahead of the consumers through S LDS
+// buffers; one s_barrier per k-tile, NO vmcnt(0) in front of it (gfx950 backs the barrier off, the producers wait for exactly the tile
+// the consumers need next: s_waitcnt vmcnt((S - 2) x pieces)).
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }      // s_waitcnt vmcnt(n), other counters unconstrained
+#define WG_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+template <class T, int WM, int WN, int TN, int NBUF, int NP>
+__global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : (NBUF == 1 ? 4 : 2)) conv_fwd16s_kernel(FwdSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (device pass only: the host pass cannot instantiate a template body that declares __amdgpu_buffer_rsrc_t locals -- its launch stub would stay undefined)
-    constexpr int TM = 2, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;       // 1 KB DMA pieces (8 rows) per wave and k-tile
+    constexpr int TM = 2, NW = WM * WN, NT = (NW + NP) * 64, BM = WM * 64, BN = WN * TN * 32;
+    constexpr int NL = NP ? NP : NW;                            // waves that copy
+    constexpr int A_IT = BM / 8 / NL, B_IT = BN / 8 / NL;       // 1 KB DMA pieces (8 rows) per copying wave and k-tile
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int WAIT_NEXT = vmcnt_imm(NBUF >= 2 ? (NBUF - 2) * (A_IT + B_IT) : 0);      // producers: everything but the newest NBUF - 2 tiles has landed
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * (A_BYTES + B_BYTES) + BM * 4];
     int* ro = reinterpret_cast<int*>(smem + NBUF * (A_BYTES + B_BYTES));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool prod = NP && wave >= NW;
+    const int lw = NP ? wave - NW : wave;                       // index among the copying waves
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_map(blockIdx.x, p.nwg);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
@@ -158,49 +172,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NBUF == 1 ? 4 : 2) conv_fwd16s_k
         const int m = m0 + r;
         ro[r] = m < p.M ? m : -1;                 // output pixel index == GEMM row (NHWC, no phases / rings here)
     }
-    // DMA rows of this lane: A rows (BM / NW) wave + 8 n + (lane >> 3); the lane copies chunk (lane & 7) ^ swz(row) of its rows
-    const int lr = lane >> 3, lj = lane & 7;
-    int ay[A_IT], ax[A_IT], ab[A_IT], acs[A_IT];
-#pragma unroll
-    for (int n = 0; n < A_IT; ++n) {
-        const int row = (BM / NW) * wave + 8 * n + lr;
-        const int m = min(m0 + row, p.M - 1);     // past the end: any valid row (never stored)
-        const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        ay[n] = oy * p.s - p.p; ax[n] = ox * p.s - p.p; ab[n] = b * p.Hi * p.Wi;
-        acs[n] = (lj ^ ((row >> 1) & 7)) * 8;
-    }
-    int bvo[B_IT];
-#pragma unroll
-    for (int n = 0; n < B_IT; ++n) {
-        const int row = (BN / NW) * wave + 8 * n + lr;
-        bvo[n] = (min(n0 + row, p.Co - 1) * p.K + (lj ^ ((row >> 1) & 7)) * 8) * 2;
-    }
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x16, (long long)p.B * p.Hi * p.Wi * p.Ci * 2);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16, (long long)p.Co * p.K * 2);
-    const int cpt = p.Ci >> 6;                     // k-tiles per filter tap
-    const int nk = p.K >> 6;
-    int avo[A_IT];
-    int f_tap = -1;
-
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        const int tap = kt / cpt, cc = kt - tap * cpt;
-        if (tap != f_tap) {                        // block-uniform: new filter tap -> redo the gather offsets
-            f_tap = tap;
-            const int ky = tap / p.k, kx = tap - ky * p.k;
-#pragma unroll
-            for (int n = 0; n < A_IT; ++n) {
-                const int iy = refl(ay[n] + ky, p.Hi), ix = refl(ax[n] + kx, p.Wi);
-                avo[n] = ((ab[n] + iy * p.Wi + ix) * p.Ci + acs[n]) * 2;
-            }
-        }
-        unsigned char* da = smem + buf * A_BYTES + ((BM / NW) * wave) * ROWB;
-        unsigned char* db = smem + NBUF * A_BYTES + buf * B_BYTES + ((BN / NW) * wave) * ROWB;
-#pragma unroll
-        for (int n = 0; n < A_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
-#pragma unroll
-        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], kt * 128, 0, 0);
-    };
-
+    if (NP) __syncthreads();                       // (the specialised loops below use bare s_barriers: make the row table visible here)
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -208,21 +180,92 @@ __global__ void __launch_bounds__(WM * WN * 64, NBUF == 1 ? 4 : 2) conv_fwd16s_k
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int cpt = p.Ci >> 6;                     // k-tiles per filter tap
+    const int nk = p.K >> 6;
 
-    if (NBUF == 2) {
-        issue(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            __syncthreads();                       // (vmcnt(0) +) barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
-            if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-            mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
+    if (!NP || prod) {
+        // DMA rows of this lane: A rows (BM / NL) lw + 8 n + (lane >> 3); the lane copies chunk (lane & 7) ^ swz(row) of its rows
+        const int lr = lane >> 3, lj = lane & 7;
+        int ay[A_IT], ax[A_IT], ab[A_IT], acs[A_IT];
+#pragma unroll
+        for (int n = 0; n < A_IT; ++n) {
+            const int row = (BM / NL) * lw + 8 * n + lr;
+            const int m = min(m0 + row, p.M - 1);     // past the end: any valid row (never stored)
+            const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            ay[n] = oy * p.s - p.p; ax[n] = ox * p.s - p.p; ab[n] = b * p.Hi * p.Wi;
+            acs[n] = (lj ^ ((row >> 1) & 7)) * 8;
         }
-    } else {
+        int bvo[B_IT];
+#pragma unroll
+        for (int n = 0; n < B_IT; ++n) {
+            const int row = (BN / NL) * lw + 8 * n + lr;
+            bvo[n] = (min(n0 + row, p.Co - 1) * p.K + (lj ^ ((row >> 1) & 7)) * 8) * 2;
+        }
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x16, (long long)p.B * p.Hi * p.Wi * p.Ci * 2);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16, (long long)p.Co * p.K * 2);
+        int avo[A_IT];
+        int f_tap = -1;
+
+        auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+            const int tap = kt / cpt, cc = kt - tap * cpt;
+            if (tap != f_tap) {                        // block-uniform: new filter tap -> redo the gather offsets
+                f_tap = tap;
+                const int ky = tap / p.k, kx = tap - ky * p.k;
+#pragma unroll
+                for (int n = 0; n < A_IT; ++n) {
+                    const int iy = refl(ay[n] + ky, p.Hi), ix = refl(ax[n] + kx, p.Wi);
+                    avo[n] = ((ab[n] + iy * p.Wi + ix) * p.Ci + acs[n]) * 2;
+                }
+            }
+            unsigned char* da = smem + buf * A_BYTES + ((BM / NL) * lw) * ROWB;
+            unsigned char* db = smem + NBUF * A_BYTES + buf * B_BYTES + ((BN / NL) * lw) * ROWB;
+#pragma unroll
+            for (int n = 0; n < A_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
+#pragma unroll
+            for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], kt * 128, 0, 0);
+        };
+
+        if (NP) {                                      // producer wave: NBUF - 1 k-tiles ahead of the consumers
+#pragma unroll
+            for (int t = 0; t < NBUF - 1; ++t)
+                if (t < nk) issue(t, t);
+            if (NBUF - 1 <= nk) __builtin_amdgcn_s_waitcnt(WAIT_NEXT);
+            else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+            WG_BARRIER();                              // tile 0 has landed
+            int ib = NBUF - 1;                         // buffer of tile kt + NBUF - 1
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + NBUF - 1 < nk) {
+                    issue(kt + NBUF - 1, ib);          // (the buffer the consumers read in iteration kt - 1)
+                    __builtin_amdgcn_s_waitcnt(WAIT_NEXT);     // tile kt + 1 has landed
+                } else {
+                    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+                }
+                ib = ib + 1 == NBUF ? 0 : ib + 1;
+                WG_BARRIER();
+            }
+        } else if (NBUF == 2) {
+            issue(0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                __syncthreads();                       // (vmcnt(0) +) barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
+                if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+                mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                issue(kt, 0);
+                __syncthreads();                       // tile kt has landed
+                mma_tile<T, TM, TN>(smem + (wm * 64) * ROWB, smem + A_BYTES + (wn * TN * 32) * ROWB, lane, acc);
+                __syncthreads();                       // every wave is done reading: the buffer may be refilled
+            }
+        }
+    } else {                                           // consumer wave
+        WG_BARRIER();
+        int cb = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            issue(kt, 0);
-            __syncthreads();                       // tile kt has landed
-            mma_tile<T, TM, TN>(smem + (wm * 64) * ROWB, smem + A_BYTES + (wn * TN * 32) * ROWB, lane, acc);
-            __syncthreads();                       // every wave is done reading: the buffer may be refilled
+            mma_tile<T, TM, TN>(smem + cb * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cb * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
+            cb = cb + 1 == NBUF ? 0 : cb + 1;
+            WG_BARRIER();                              // this buffer may be refilled / the next tile has landed
         }
     }
 
@@ -235,6 +278,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NBUF == 1 ? 4 : 2) conv_fwd16s_k
         const int l31 = lane & 31, lh = lane >> 5;
         float2* red = reinterpret_cast<float2*>(smem);
         __syncthreads();                           // every wave is done with the operand buffers
+        if (!prod) {
         // (one column block per call with a COMPILE-TIME j: as a `#pragma unroll` loop over j the 2 x 4 tile's body is unrolled too late
         //  for the accumulator array to be split into registers again -- it then lives in scratch through the whole main loop)
         auto col = [&](auto jc) __attribute__((always_inline)) {
@@ -265,6 +309,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NBUF == 1 ? 4 : 2) conv_fwd16s_k
         col(std::integral_constant<int, 0>{});
         if constexpr (TN > 1) col(std::integral_constant<int, 1>{});
         if constexpr (TN > 2) { col(std::integral_constant<int, 2>{}); col(std::integral_constant<int, 3>{}); }
+        }
         __syncthreads();
         if (tid < BN && n0 + tid < p.Co) {
             float cnt = 64.f, mean = red[tid].x, m2 = red[tid].y;
@@ -278,8 +323,8 @@ __global__ void __launch_bounds__(WM * WN * 64, NBUF == 1 ? 4 : 2) conv_fwd16s_k
             }
             p.stats[(size_t)(m0 / BM) * p.Co + n0 + tid] = make_float2(mean, m2);
         }
-        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Co, p.Co, p.y, p.yst, lane, [](float v, int) { return v; });
-    } else {
+        if (!prod) store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Co, p.Co, p.y, p.yst, lane, [](float v, int) { return v; });
+    } else if (!prod) {
         store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Co, p.Co, p.y, p.yst, lane,
                           [&](float v, int n) { return act_apply(v + (bias ? bias[n] : 0.f), act); });
     }
@@ -302,25 +347,38 @@ int glds_tile(int rows, int N) {
     return 1;
 }
 
+// ACLGAN_GLDS_SPEC = 1: the wave-specialised kernels instead of the unified ones (every wave copies and multiplies).  Measured: the
+// specialised 128 x 128 kernel is SLOWER (ResBlock forward 69 vs 54 us; bf16 step 65.5 vs 57.2 ms), the 256 x 128 one wins isolated
+// (50.3 vs 52.7 us) and loses in the step (60.1 vs 57.2 ms) -- profiles/r03_experiments.md; kept as a tested option
+int g_spec = -1;
+bool glds_spec() {
+    if (g_spec < 0) { const char* e = getenv("ACLGAN_GLDS_SPEC"); g_spec = e ? atoi(e) : 0; }
+    return g_spec != 0;
+}
+
 template <class T>
 int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
     const int tc = glds_tile(g.M, g.Co);
     static int force = -1;
     if (force < 0) { const char* e = getenv("ACLGAN_GLDS_NBUF"); force = e ? atoi(e) : 0; }
+    const bool sp = glds_spec();
     if (tc == 3) {
         p.tiles_n = g.Co / 256; p.nwg = cdiv(g.M, 256) * p.tiles_n;
-        hipLaunchKernelGGL((conv_fwd16s_kernel<T, 4, 2, 4, 2>), dim3(p.nwg), dim3(512), 0, st, p);
+        hipLaunchKernelGGL((conv_fwd16s_kernel<T, 4, 2, 4, 2, 0>), dim3(p.nwg), dim3(512), 0, st, p);
     } else if (tc == 2) {
         p.tiles_n = g.Co / 128; p.nwg = cdiv(g.M, 256) * p.tiles_n;
-        hipLaunchKernelGGL((conv_fwd16s_kernel<T, 4, 2, 2, 2>), dim3(p.nwg), dim3(512), 0, st, p);
+        if (sp) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 4, 2, 2, 3, 4>), dim3(p.nwg), dim3(768), 0, st, p);      // 8 consumers + 4 producers, 3 x 48 KB
+        else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 4, 2, 2, 2, 0>), dim3(p.nwg), dim3(512), 0, st, p);
     } else {
         const int BN = g.Co % 128 == 0 ? 128 : 64;
         p.tiles_n = g.Co / BN; p.nwg = cdiv(g.M, 128) * p.tiles_n;
         // (the single-buffer variant, 4 workgroups per CU, wins on ISOLATED large grids -- B=32 ResBlock shape 173 vs 200 us -- but loses
         //  badly inside the step: fp16 B=32 step 237.6 vs 185.0 ms, profiles/r03_experiments.md; ACLGAN_GLDS_NBUF=1 selects it)
-        if (BN == 128 && force != 1) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 2, 2>), dim3(p.nwg), dim3(256), 0, st, p);
-        else if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 2, 1>), dim3(p.nwg), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 1, 2>), dim3(p.nwg), dim3(256), 0, st, p);
+        if (BN == 128 && force == 1) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 2, 1, 0>), dim3(p.nwg), dim3(256), 0, st, p);
+        else if (BN == 128 && sp) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 2, 2, 2>), dim3(p.nwg), dim3(384), 0, st, p);      // 4 consumers + 2 producers, 2 x 32 KB, 2 workgroups per CU
+        else if (BN == 128) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 2, 2, 0>), dim3(p.nwg), dim3(256), 0, st, p);
+        else if (sp) hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 1, 2, 2>), dim3(p.nwg), dim3(384), 0, st, p);
+        else hipLaunchKernelGGL((conv_fwd16s_kernel<T, 2, 2, 1, 2, 0>), dim3(p.nwg), dim3(256), 0, st, p);
     }
     ACL_CHECK_LAUNCH("conv_fwd16s_kernel");
     return ACLGAN_OK;
@@ -334,16 +392,21 @@ struct DgSP {
     int B, Ho, Wo, Co, Ci, k, s, Hp, Wp, Hc, Wc, Mc, tiles_n, nwg, pst;
 };
 
-template <class T, int WM, int WN, int TN>
-__global__ void __launch_bounds__(WM * WN * 64, 2) conv_dgrad16s_kernel(DgSP p) {
+template <class T, int WM, int WN, int TN, int NBUF, int NP>
+__global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : 2) conv_dgrad16s_kernel(DgSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (device pass only, see conv_fwd16s_kernel)
-    constexpr int TM = 2, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
+    constexpr int TM = 2, NW = WM * WN, NT = (NW + NP) * 64, BM = WM * 64, BN = WN * TN * 32;
+    constexpr int NL = NP ? NP : NW;
+    constexpr int A_IT = BM / 8 / NL, B_IT = BN / 8 / NL;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES) + BM * 4];
-    int* ro = reinterpret_cast<int*>(smem + 2 * (A_BYTES + B_BYTES));
+    constexpr int WAIT_NEXT = vmcnt_imm(NBUF >= 2 ? (NBUF - 2) * (A_IT + B_IT) : 0);      // producers: everything but the newest NBUF - 2 tiles has landed
+    static_assert(NP || NBUF == 2, "the unified loop is double-buffered");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * (A_BYTES + B_BYTES) + BM * 4];
+    int* ro = reinterpret_cast<int*>(smem + NBUF * (A_BYTES + B_BYTES));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool prod = NP && wave >= NW;
+    const int lw = NP ? wave - NW : wave;
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_map(blockIdx.x, p.nwg);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
@@ -361,53 +424,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_dgrad16s_kernel(DgSP p) 
         }
         ro[r] = oo;
     }
-    const int lr = lane >> 3, lj = lane & 7;
-    int ay[A_IT], ax[A_IT], ab[A_IT], acs[A_IT];
-#pragma unroll
-    for (int n = 0; n < A_IT; ++n) {
-        const int row = (BM / NW) * wave + 8 * n + lr;
-        const int m = m0 + row;
-        if (m < p.Mc) {
-            const int b = m / hwc, rem = m - b * hwc, y2 = rem / p.Wc;
-            ay[n] = y2; ax[n] = rem - y2 * p.Wc; ab[n] = b;
-        } else { ay[n] = -100000; ax[n] = -100000; ab[n] = 0; }      // reads zero for every tap
-        acs[n] = (lj ^ ((row >> 1) & 7)) * 8;
-    }
-    // B rows = input channels n, k = 64 consecutive cout of one tap: w16t[tap][n][cout]
-    int bvo[B_IT];
-#pragma unroll
-    for (int n = 0; n < B_IT; ++n) {
-        const int row = (BN / NW) * wave + 8 * n + lr;
-        bvo[n] = (min(n0 + row, p.Ci - 1) * p.Co + (lj ^ ((row >> 1) & 7)) * 8) * 2;
-    }
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy16, (long long)p.B * p.Ho * p.Wo * p.Co * 2);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16t, (long long)p.k * p.k * p.Ci * p.Co * 2);
-    const int cpt = p.Co >> 6;
-    const int nk = Ty * Tx * cpt;
-    int avo[A_IT];
-    int f_tap = -1, tapoff = 0;
-
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        const int t = kt / cpt, cc = kt - t * cpt;
-        if (t != f_tap) {
-            f_tap = t;
-            const int ty = t / Tx, tx = t - ty * Tx;
-            tapoff = ((cy + p.s * ty) * p.k + (cx + p.s * tx)) * p.Ci * p.Co * 2;
-#pragma unroll
-            for (int n = 0; n < A_IT; ++n) {
-                const int oy = ay[n] - ty, ox = ax[n] - tx;
-                const bool ok = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
-                avo[n] = ok ? (((ab[n] * p.Ho + oy) * p.Wo + ox) * p.Co + acs[n]) * 2 : OOB;
-            }
-        }
-        unsigned char* da = smem + buf * A_BYTES + ((BM / NW) * wave) * ROWB;
-        unsigned char* db = smem + 2 * A_BYTES + buf * B_BYTES + ((BN / NW) * wave) * ROWB;
-#pragma unroll
-        for (int n = 0; n < A_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
-#pragma unroll
-        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], tapoff + cc * 128, 0, 0);
-    };
-
+    if (NP) __syncthreads();
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -415,15 +432,92 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) conv_dgrad16s_kernel(DgSP p) 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int cpt = p.Co >> 6;
+    const int nk = Ty * Tx * cpt;
 
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-        mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + 2 * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
+    if (!NP || prod) {
+        const int lr = lane >> 3, lj = lane & 7;
+        int ay[A_IT], ax[A_IT], ab[A_IT], acs[A_IT];
+#pragma unroll
+        for (int n = 0; n < A_IT; ++n) {
+            const int row = (BM / NL) * lw + 8 * n + lr;
+            const int m = m0 + row;
+            if (m < p.Mc) {
+                const int b = m / hwc, rem = m - b * hwc, y2 = rem / p.Wc;
+                ay[n] = y2; ax[n] = rem - y2 * p.Wc; ab[n] = b;
+            } else { ay[n] = -100000; ax[n] = -100000; ab[n] = 0; }      // reads zero for every tap
+            acs[n] = (lj ^ ((row >> 1) & 7)) * 8;
+        }
+        // B rows = input channels n, k = 64 consecutive cout of one tap: w16t[tap][n][cout]
+        int bvo[B_IT];
+#pragma unroll
+        for (int n = 0; n < B_IT; ++n) {
+            const int row = (BN / NL) * lw + 8 * n + lr;
+            bvo[n] = (min(n0 + row, p.Ci - 1) * p.Co + (lj ^ ((row >> 1) & 7)) * 8) * 2;
+        }
+        const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy16, (long long)p.B * p.Ho * p.Wo * p.Co * 2);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16t, (long long)p.k * p.k * p.Ci * p.Co * 2);
+        int avo[A_IT];
+        int f_tap = -1, tapoff = 0;
+
+        auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+            const int t = kt / cpt, cc = kt - t * cpt;
+            if (t != f_tap) {
+                f_tap = t;
+                const int ty = t / Tx, tx = t - ty * Tx;
+                tapoff = ((cy + p.s * ty) * p.k + (cx + p.s * tx)) * p.Ci * p.Co * 2;
+#pragma unroll
+                for (int n = 0; n < A_IT; ++n) {
+                    const int oy = ay[n] - ty, ox = ax[n] - tx;
+                    const bool ok = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+                    avo[n] = ok ? (((ab[n] * p.Ho + oy) * p.Wo + ox) * p.Co + acs[n]) * 2 : OOB;
+                }
+            }
+            unsigned char* da = smem + buf * A_BYTES + ((BM / NL) * lw) * ROWB;
+            unsigned char* db = smem + NBUF * A_BYTES + buf * B_BYTES + ((BN / NL) * lw) * ROWB;
+#pragma unroll
+            for (int n = 0; n < A_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(da + n * 8 * ROWB), 16, avo[n], cc * 128, 0, 0);
+#pragma unroll
+            for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], tapoff + cc * 128, 0, 0);
+        };
+
+        if (NP) {                                      // producer wave (see conv_fwd16s_kernel)
+#pragma unroll
+            for (int t = 0; t < NBUF - 1; ++t)
+                if (t < nk) issue(t, t);
+            if (NBUF - 1 <= nk) __builtin_amdgcn_s_waitcnt(WAIT_NEXT);
+            else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+            WG_BARRIER();
+            int ib = NBUF - 1;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + NBUF - 1 < nk) {
+                    issue(kt + NBUF - 1, ib);
+                    __builtin_amdgcn_s_waitcnt(WAIT_NEXT);
+                } else {
+                    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+                }
+                ib = ib + 1 == NBUF ? 0 : ib + 1;
+                WG_BARRIER();
+            }
+        } else {
+            issue(0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                __syncthreads();
+                if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+                mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
+            }
+        }
+    } else {                                           // consumer wave
+        WG_BARRIER();
+        int cb = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            mma_tile<T, TM, TN>(smem + cb * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cb * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
+            cb = cb + 1 == NBUF ? 0 : cb + 1;
+            WG_BARRIER();
+        }
     }
-    store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Ci, p.Ci, p.dxp, p.pst, lane, [](float v, int) { return v; });
+    if (!prod) store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Ci, p.Ci, p.dxp, p.pst, lane, [](float v, int) { return v; });
 #endif
 }
 
@@ -431,18 +525,22 @@ template <class T>
 int launch_dgrad16s(const ConvGeom& g, DgSP p, hipStream_t st) {
     const int tc = glds_tile(p.Mc * g.s * g.s, g.Ci);      // (rows of all stride-parity classes together fill the chip)
     const dim3 z(1, 1, g.s * g.s);
+    const bool sp = glds_spec();
     if (tc == 3) {
         p.tiles_n = g.Ci / 256; p.nwg = cdiv(p.Mc, 256) * p.tiles_n;
-        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 4, 2, 4>), dim3(p.nwg, 1, z.z), dim3(512), 0, st, p);
+        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 4, 2, 4, 2, 0>), dim3(p.nwg, 1, z.z), dim3(512), 0, st, p);
     } else if (tc == 2) {
         p.tiles_n = g.Ci / 128; p.nwg = cdiv(p.Mc, 256) * p.tiles_n;
-        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 4, 2, 2>), dim3(p.nwg, 1, z.z), dim3(512), 0, st, p);
+        if (sp) hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 4, 2, 2, 3, 4>), dim3(p.nwg, 1, z.z), dim3(768), 0, st, p);
+        else hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 4, 2, 2, 2, 0>), dim3(p.nwg, 1, z.z), dim3(512), 0, st, p);
     } else if (g.Ci % 128 == 0) {
         p.tiles_n = g.Ci / 128; p.nwg = cdiv(p.Mc, 128) * p.tiles_n;
-        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 2>), dim3(p.nwg, 1, z.z), dim3(256), 0, st, p);
+        if (sp) hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 2, 2, 2>), dim3(p.nwg, 1, z.z), dim3(384), 0, st, p);
+        else hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 2, 2, 0>), dim3(p.nwg, 1, z.z), dim3(256), 0, st, p);
     } else {
         p.tiles_n = g.Ci / 64; p.nwg = cdiv(p.Mc, 128) * p.tiles_n;
-        hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 1>), dim3(p.nwg, 1, z.z), dim3(256), 0, st, p);
+        if (sp) hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 1, 2, 2>), dim3(p.nwg, 1, z.z), dim3(384), 0, st, p);
+        else hipLaunchKernelGGL((conv_dgrad16s_kernel<T, 2, 2, 1, 2, 0>), dim3(p.nwg, 1, z.z), dim3(256), 0, st, p);
     }
     ACL_CHECK_LAUNCH("conv_dgrad16s_kernel");
     return ACLGAN_OK;

@@ -17,6 +17,7 @@
 // pipeline on dy with ZERO padding and the flipped / transposed filter for the interior of dx (the halo ring of the padded grid
 // keeps its small direct launch, conv_fast.hip mode 2).  The weight gradient stays on the direct kernel.
 #include "common.h"
+#include "st16.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -99,12 +100,14 @@ __device__ __forceinline__ void at4(const F (&m)[6], F (&y)[4]) {
 
 // U[f][row][k]: forward: row = cout, k = cin from w[cout][ky][kx][cin];
 // dgrad (flip = 1): row = cin, k = cout from the flipped filter w[cout][2-ky][2-kx][cin]
-__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int flip) {
+// planes > 0 (elements per plane): U is written as the three bf16 planes of the split-bf16 GEMM (gemm_bf16x3.hip) instead of fp32
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int flip, int64_t planes) {
     // one thread = one (row, k) pair of the OUTPUT layout, k fastest: forward (row = cout, k = cin) reads w coalesced along cin;
     // dgrad (row = cin, k = cout, flipped taps) reads w with stride 9*Cin -- 9 strided loads per thread against 36 coalesced stores
     const int R = flip ? Ci : Co, K = flip ? Co : Ci;
     const int64_t n = (int64_t)R * K;
     w += (size_t)blockIdx.y * Co * 9 * Ci;        // blockIdx.y = phase (merged filters of the sub-pixel layers), else 0
+    unsigned short* U16 = reinterpret_cast<unsigned short*>(U) + (size_t)blockIdx.y * 36 * n;
     U += (size_t)blockIdx.y * 36 * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int kk = (int)(i % K), row = (int)(i / K);
@@ -128,7 +131,16 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restric
             float o[6];
             g6(t[a], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) U[((size_t)(a * 6 + j) * R + row) * K + kk] = o[j];
+            for (int j = 0; j < 6; ++j) {
+                const size_t at = ((size_t)(a * 6 + j) * R + row) * K + kk;
+                if (planes) {
+                    unsigned short h, m, l;
+                    split3(o[j], h, m, l);
+                    U16[at] = h; U16[at + planes] = m; U16[at + 2 * planes] = l;
+                } else {
+                    U[at] = o[j];
+                }
+            }
         }
     }
 }
@@ -146,14 +158,17 @@ WView phase_view(int Hv, int Wv, int py, int px, int Hf, int Wf) { WView v = {Hv
 
 // V[ph][f][t][c] = (B^T d B)[f] of the 6x6 patch of tile t = (b, ty, tx) of view ph: logical rows 4ty+off .. 4ty+off+5; positions
 // outside the view are reflected (reflect = 1: the forward's ReflectionPad2d) or read as zero.  blockIdx.y = phase.
+// planes > 0 (elements per plane = nph * 36 * T * C): V is written as three bf16 planes (h, m, l with v = h + m + l, st16.h split3) for the
+// split-bf16 GEMM instead of fp32: 6 bytes per value instead of 4
 template <int NV>
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, WViews vs, int C, int TY, int TX, int off,
-                                                         int reflect) {
+                                                         int reflect, int64_t planes) {
     typedef typename VecOf<NV>::T F;
     const WView v = vs.v[blockIdx.y];
     const int Cv = C / NV;
     const int64_t T = (int64_t)B * TY * TX, n = T * Cv;
     float* Vp = V + (size_t)blockIdx.y * 36 * T * C;
+    unsigned short* Vq = reinterpret_cast<unsigned short*>(V) + (size_t)blockIdx.y * 36 * T * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % Cv) * NV;
         const int64_t t = i / Cv;
@@ -183,7 +198,30 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
             F o[6];
             bt6(tmp[r], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<F*>(Vp + ((size_t)(r * 6 + j) * T + t) * C + c) = o[j];
+            for (int j = 0; j < 6; ++j) {
+                const size_t at = ((size_t)(r * 6 + j) * T + t) * C + c;
+                if (planes) {
+                    if constexpr (NV == 1) {
+                        unsigned short h, m, l;
+                        split3(o[j], h, m, l);
+                        Vq[at] = h; Vq[at + planes] = m; Vq[at + 2 * planes] = l;
+                    } else {
+                        typedef unsigned int U __attribute__((ext_vector_type(NV / 2)));
+                        U ph, pm, pl;
+#pragma unroll
+                        for (int e = 0; e < NV; e += 2) {
+                            unsigned short h0, m0, l0, h1, m1, l1;
+                            split3(o[j][e], h0, m0, l0); split3(o[j][e + 1], h1, m1, l1);
+                            const unsigned int wh = h0 | ((unsigned int)h1 << 16), wm = m0 | ((unsigned int)m1 << 16), wl = l0 | ((unsigned int)l1 << 16);
+                            if constexpr (NV == 2) { ph = wh; pm = wm; pl = wl; }
+                            else { ph[e / 2] = wh; pm[e / 2] = wm; pl[e / 2] = wl; }
+                        }
+                        *reinterpret_cast<U*>(Vq + at) = ph; *reinterpret_cast<U*>(Vq + at + planes) = pm; *reinterpret_cast<U*>(Vq + at + 2 * planes) = pl;
+                    }
+                } else {
+                    *reinterpret_cast<F*>(Vp + at) = o[j];
+                }
+            }
         }
     }
 }
@@ -412,12 +450,30 @@ int wino_vec() {
     if (v < 0) { const char* e = getenv("ACLGAN_WINO_VEC"); v = e ? atoi(e) : 2; if (v != 1 && v != 2 && v != 4) v = 2; }
     return v;
 }
-int launch_wino_input(const float* x, float* V, int B, const WViews& vs, int nph, int C, int TY, int TX, int off, int reflect, hipStream_t st) {
-    const int nv = wino_vec();
+// split-bf16 GEMM slices (gemm_bf16x3.hip) for the forward-type products: ACLGAN_WINO_X3=1 / aclgan_set_tuning("wino_x3", 1).  OFF by
+// default: the launch itself is 1.6x faster than the fp32 MFMA slices at fp32 accuracy (ResBlock shape 67.8 against 113 us isolated, 81
+// against 102 us in the step: -8.4 ms of GEMM time per step), but the step does not get faster -- the transform writes 6 instead of 4
+// bytes per value (+3.7 ms), the weight gradient loses the kept fp32 V (+1.6 ms) and, measured on the same box back to back, every
+// OTHER matrix kernel of the step runs 5-8 % slower while these launches are in the mix (the chip is power-limited: the bf16 pipes at
+// full rate cost the clocks of what follows): 121.3 against 119.9 ms of kernel time per step (profiles/r03_experiments.md).
+int g_wino_x3 = -1;
+bool wino_x3() {
+    if (g_wino_x3 < 0) { const char* e = getenv("ACLGAN_WINO_X3"); g_wino_x3 = e ? (atoi(e) ? 1 : 0) : 0; }
+    return g_wino_x3 == 1;
+}
+// channels per thread of the input transform when it writes the three bf16 planes (ACLGAN_WINO_VEC3)
+int wino_vec3() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_WINO_VEC3"); v = e ? atoi(e) : 2; if (v != 1 && v != 2 && v != 4) v = 2; }
+    return v;
+}
+// planes: 0 = fp32 V; else the element count of one bf16 plane (3-plane output)
+int launch_wino_input(const float* x, float* V, int B, const WViews& vs, int nph, int C, int TY, int TX, int off, int reflect, hipStream_t st, int64_t planes = 0) {
+    const int nv = planes ? wino_vec3() : wino_vec();
     const dim3 grid(grid_for((int64_t)B * TY * TX * (C / nv), 16384), nph);
-    if (nv == 4) hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect);
-    else if (nv == 2) hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect);
-    else hipLaunchKernelGGL(wino_input_kernel<1>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect);
+    if (nv == 4) hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect, planes);
+    else if (nv == 2) hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect, planes);
+    else hipLaunchKernelGGL(wino_input_kernel<1>, grid, dim3(256), 0, st, x, V, B, vs, C, TY, TX, off, reflect, planes);
     ACL_CHECK_LAUNCH("wino_input_kernel");
     return ACLGAN_OK;
 }
@@ -475,16 +531,20 @@ bool conv_wino_ok(const ConvGeom& g) {
     return wino_enabled() && g.k == 3 && g.s == 1 && g.p == 1 && g.up == 0 && g.Ho % 4 == 0 && g.Wo % 4 == 0 && g.Ci % 16 == 0 && g.Co % 16 == 0 &&
            (int64_t)g.Ci * g.Co >= 64 * 64;
 }
+// (U and V slots are sized for the three bf16 planes of the split-bf16 GEMM -- 6 bytes per value -- whether or not it runs; a layer's
+//  cached U is fp32 or planes for the whole update: the choice depends on the layer's shape and the process-wide switch only)
+// tuning / test knob behind aclgan_set_tuning("wino_x3", v); returns the previous value
+int set_wino_x3(int v) { const int old = wino_x3() ? 1 : 0; g_wino_x3 = v ? 1 : 0; return old; }
 size_t conv_wino_u_bytes(const ConvGeom& g) {
-    if (conv_wino_ok(g)) return align256((size_t)36 * g.Co * g.Ci * sizeof(float));
-    if (conv_up5_wino_ok(g)) return align256((size_t)144 * g.Co * g.Ci * sizeof(float));
+    if (conv_wino_ok(g)) return align256((size_t)36 * g.Co * g.Ci * 6);
+    if (conv_up5_wino_ok(g)) return align256((size_t)144 * g.Co * g.Ci * 6);
     return 0;
 }
 size_t conv_wino_scratch_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g)) return 0;
     const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
     const int cmax = std::max(g.Ci, g.Co);      // forward: V has Cin, M has Cout channels; dgrad the other way round
-    return align256((size_t)36 * g.Co * g.Ci * sizeof(float)) + 2 * align256((size_t)36 * T * cmax * sizeof(float)) + 256;
+    return align256((size_t)36 * g.Co * g.Ci * 6) + align256((size_t)36 * T * cmax * 6) + align256((size_t)36 * T * cmax * sizeof(float)) + 256;
 }
 namespace {
 // filter transform -> input transform -> 36 GEMMs -> output transform.  `in` has Cin_ channels, `out` Cout_.
@@ -493,20 +553,23 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
     const int TY = H / 4, TX = W / 4;
     const int64_t T = (int64_t)B * TY * TX;
     char* cur = (char*)scratch;
-    float* U = take(cur, (size_t)36 * Cout_ * Cin_ * 4);
-    float* V = take(cur, (size_t)36 * T * Cin_ * 4);
+    const bool x3 = !keepV && wino_x3() && gemm_x3_shape_ok((int)T, Cin_, Cout_);      // (a kept V feeds the fp32 weight-gradient GEMM: fp32)
+    const size_t eb = x3 ? 6 : 4;
+    float* U = take(cur, (size_t)36 * Cout_ * Cin_ * 6);
+    float* V = take(cur, (size_t)36 * T * Cin_ * eb);
     float* M = take(cur, (size_t)36 * T * Cout_ * 4);
     if (keepV) V = keepV;         // the caller keeps the input transform for the weight gradient of the same layer
     const WViews vw = one_view(ident_view(H, W));
+    const int64_t uplanes = x3 ? (int64_t)36 * Cout_ * Cin_ : 0, vplanes = x3 ? (int64_t)36 * T * Cin_ : 0;
     bool fresh = true;
-    U = cached_u(U, w, flip ? 1 : 0, (size_t)36 * Cout_ * Cin_ * 4, &fresh);
+    U = cached_u(U, w, flip ? 1 : 0, (size_t)36 * Cout_ * Cin_ * eb, &fresh);
     if (fresh) {
-        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip, uplanes);
         ACL_CHECK_LAUNCH("wino_filter_kernel");
     }
-    int rc = launch_wino_input(in, V, B, vw, 1, Cin_, TY, TX, -1, reflect, st);
+    int rc = launch_wino_input(in, V, B, vw, 1, Cin_, TY, TX, -1, reflect, st, vplanes);
     if (rc) return rc;
-    rc = gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, 0, st);
+    rc = x3 ? gemm_slices_x3(V, (size_t)vplanes * 2, U, (size_t)uplanes * 2, M, (int)T, Cin_, Cout_, 36, 0, st) : gemm_slices_f32(V, U, M, (int)T, Cin_, Cout_, 36, 0, st);
     if (rc) return rc;
     return launch_wino_output(M, bias, out, B, vw, Cout_, TY, TX, act, accumulate, 0, st, stats);
 }
@@ -516,6 +579,7 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
 // input transform
 size_t conv_wino_keep_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
+    if (wino_x3() && gemm_x3_shape_ok(1, g.Ci, g.Co)) return 0;      // the forward writes V as bf16 planes; the fp32 weight-gradient GEMM transforms x itself
     return align256((size_t)36 * g.B * (g.Ho / 4) * (g.Wo / 4) * g.Ci * sizeof(float));
 }
 int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats, float* keepV) {
@@ -591,10 +655,11 @@ Up5Geo up5_geo(const ConvGeom& g) {
 size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g)) return 0;
     const Up5Geo q = up5_geo(g);
-    return align256((size_t)144 * g.Co * g.Ci * 4) + align256((size_t)36 * q.T * g.Ci * 4) + align256((size_t)144 * q.T * g.Co * 4) + 256;
+    return align256((size_t)144 * g.Co * g.Ci * 6) + align256((size_t)36 * q.T * g.Ci * 6) + align256((size_t)144 * q.T * g.Co * 4) + 256;
 }
 size_t conv_up5_wino_keep_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
+    if (wino_x3() && gemm_x3_shape_ok(1, g.Ci, g.Co)) return 0;
     return align256((size_t)36 * up5_geo(g).T * g.Ci * sizeof(float));
 }
 int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV,
@@ -602,19 +667,23 @@ int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp,
     if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
-    float* U = take(cur, (size_t)144 * g.Co * g.Ci * 4);
-    float* V = take(cur, (size_t)36 * q.T * g.Ci * 4);
+    const bool x3 = !keepV && wino_x3() && gemm_x3_shape_ok((int)q.T, g.Ci, g.Co);
+    const size_t eb = x3 ? 6 : 4;
+    float* U = take(cur, (size_t)144 * g.Co * g.Ci * 6);
+    float* V = take(cur, (size_t)36 * q.T * g.Ci * 6);
     float* M = take(cur, (size_t)144 * q.T * g.Co * 4);
     if (keepV) V = keepV;
+    const int64_t uplanes = x3 ? (int64_t)144 * g.Co * g.Ci : 0, vplanes = x3 ? (int64_t)36 * q.T * g.Ci : 0;
     bool fresh = true;
-    U = cached_u(U, wkey, 2, (size_t)144 * g.Co * g.Ci * 4, &fresh);
+    U = cached_u(U, wkey, 2, (size_t)144 * g.Co * g.Ci * eb, &fresh);
     if (fresh) {
-        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0, uplanes);
         ACL_CHECK_LAUNCH("wino_filter_kernel(up5)");
     }
-    int rc = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st);
+    int rc = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st, vplanes);
     if (rc) return rc;
-    rc = gemm_slices_f32(V, U, M, (int)q.T, g.Ci, g.Co, 144, 36, st);      // the 4 phases share V: A offset = (f % 36) planes
+    // the 4 phases share V: A operand of slice f = slice f % 36
+    rc = x3 ? gemm_slices_x3(V, (size_t)vplanes * 2, U, (size_t)uplanes * 2, M, (int)q.T, g.Ci, g.Co, 144, 36, st) : gemm_slices_f32(V, U, M, (int)q.T, g.Ci, g.Co, 144, 36, st);
     if (rc) return rc;
     return launch_wino_output(M, bias, y, g.B, q.ph, g.Co, q.TY, q.TX, g.act, 0, 0, st);
 }
@@ -622,25 +691,28 @@ int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp,
 size_t conv_up5_wino_dgrad_scratch_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g)) return 0;
     const Up5Geo q = up5_geo(g);
-    return align256((size_t)144 * g.Co * g.Ci * 4) + align256((size_t)144 * q.Td * g.Co * 4) + align256((size_t)144 * q.Td * g.Ci * 4) + 256;
+    return align256((size_t)144 * g.Co * g.Ci * 6) + align256((size_t)144 * q.Td * g.Co * 6) + align256((size_t)144 * q.Td * g.Ci * 4) + 256;
 }
 int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* wp, float* dx, int accumulate, void* scratch, hipStream_t st, const float* wkey) {
     if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
-    float* U = take(cur, (size_t)144 * g.Co * g.Ci * 4);
-    float* V = take(cur, (size_t)144 * q.Td * g.Co * 4);
+    const bool x3 = wino_x3() && gemm_x3_shape_ok((int)q.Td, g.Co, g.Ci);
+    const size_t eb = x3 ? 6 : 4;
+    float* U = take(cur, (size_t)144 * g.Co * g.Ci * 6);
+    float* V = take(cur, (size_t)144 * q.Td * g.Co * 6);
     float* M = take(cur, (size_t)144 * q.Td * g.Ci * 4);
+    const int64_t uplanes = x3 ? (int64_t)144 * g.Co * g.Ci : 0, vplanes = x3 ? (int64_t)144 * q.Td * g.Co : 0;
     bool fresh = true;
-    U = cached_u(U, wkey, 3, (size_t)144 * g.Co * g.Ci * 4, &fresh);
+    U = cached_u(U, wkey, 3, (size_t)144 * g.Co * g.Ci * eb, &fresh);
     if (fresh) {
-        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1, uplanes);
         ACL_CHECK_LAUNCH("wino_filter_kernel(up5 dgrad)");
     }
     // dx[u] = sum_k wflip[k] dy_phase[u - 2 + k]: patches start 2 before the tile, zero outside the 62 x 62 phase view
-    int rc = launch_wino_input(dy, V, g.B, q.ph, 4, g.Co, q.TYd, q.TXd, -2, 0, st);
+    int rc = launch_wino_input(dy, V, g.B, q.ph, 4, g.Co, q.TYd, q.TXd, -2, 0, st, vplanes);
     if (rc) return rc;
-    rc = gemm_slices_f32(V, U, M, (int)q.Td, g.Co, g.Ci, 144, 0, st);
+    rc = x3 ? gemm_slices_x3(V, (size_t)vplanes * 2, U, (size_t)uplanes * 2, M, (int)q.Td, g.Co, g.Ci, 144, 0, st) : gemm_slices_f32(V, U, M, (int)q.Td, g.Co, g.Ci, 144, 0, st);
     if (rc) return rc;
     WViews dst = one_view(ident_view(g.Hi, g.Wi));
     dst.nph = 4;

@@ -67,6 +67,15 @@ __device__ __forceinline__ unsigned int st_pack2(float a, float b, int st) {
     if (st == ST_BF16) return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, st_bf16x2));
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, st_f16x2));
 }
+// fp32 -> three bf16 numbers with x = h + m + l to 2^-26 |x| (csrc/gemm_bf16x3.hip): both differences are exact in fp32
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)x;
+    const float r1 = x - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, bl);
+}
 // byte offset of element i
 __host__ __device__ __forceinline__ const void* st_at(const void* p, int64_t i, int st) { return (const char*)p + i * st_bytes(st); }
 __host__ __device__ __forceinline__ void* st_at(void* p, int64_t i, int st) { return (char*)p + i * st_bytes(st); }

@@ -118,6 +118,13 @@ long long aclgan_launch_count(void);
  * 3x3 convolutions (networks.py:297-310) spends its MFMA time in, exposed alone so that bench.py can time the step's dominant
  * kernel with HIP events and tests can check it against torch.bmm.  K % 16 == 0. */
 int aclgan_gemm_slices_f32(const float* A, const float* B, float* C, int T, int K, int N, int nslices, void* stream);
+/* The same product with fp32 accuracy on the bf16 matrix cores (round 3, csrc/gemm_bf16x3.hip): each fp32 operand is split EXACTLY into
+ * three bf16 numbers (h + m + l), six of the nine cross products (everything above 2^-24 of the product) are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16.  This entry point splits A and B into `scratch` (aclgan_gemm_slices_x3_scratch_bytes) and runs the kernel; the
+ * step's Winograd transforms write the split planes directly.  A == B == NULL: reuse the planes an earlier call left in scratch (timing
+ * the GEMM launch alone).  K % 32 == 0, N % 64 == 0, else ACLGAN_EUNSUPPORTED. */
+size_t aclgan_gemm_slices_x3_scratch_bytes(int T, int K, int N, int nslices);
+int aclgan_gemm_slices_x3(const float* A, const float* B, float* C, int T, int K, int N, int nslices, void* scratch, void* stream);
 const char* aclgan_last_error(void);
 /* Deterministic mode (process-wide; also ACLGAN_DETERMINISTIC=1; the counterpart of torch.use_deterministic_algorithms, which the
  * reference never turns on -- its cuDNN backward is not reproducible either, train.py:29 sets cudnn.benchmark = True).
@@ -282,7 +289,9 @@ int aclgan_conv16s_ok(const aclgan_conv_desc* d, int which);
 int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, const void* w16, const float* bias, void* y, int y_storage, void* stream);
 /* Process-wide tuning knobs that also exist as environment variables, settable at run time (tests use this to run every tile shape of
  * csrc/conv_glds16.hip).  key "glds_tile": 0 / 1 = 128-row tiles (default), 2 = 256 x 128, 3 = 256 x 256 where the shape allows, 4 = the
- * largest tile that still fills the chip.  Returns the previous value, -1 for an unknown key.  Not thread-safe against running launches. */
+ * largest tile that still fills the chip.  key "wino_x3": 1 = the GEMM slices of the fp32 Winograd pipeline run as split-bf16
+ * products on the bf16 matrix cores (fp32-accurate, see aclgan_gemm_slices_x3), 0 (default) = on the fp32 MFMA kernel.
+ * Returns the previous value, -1 for an unknown key.  Not thread-safe against running launches. */
 int aclgan_set_tuning(const char* key, int value);
 /* The same launch with the normalisation statistics taken from its epilogue (round 3; replaces the norm_stats pass over y that
  * follows the conv in reference networks.py:382-395 Conv2dBlock.forward -> self.norm).  aclgan_conv2d_fwd16s_stats_chunk = rows R per

@@ -332,3 +332,37 @@ def test_gemm_slices_f32_vs_bmm(L, T_, K, N, ns):
     L.check(L.lib.aclgan_gemm_slices_f32(L.ptr(A), L.ptr(Bm), L.ptr(Cm), T_, K, N, ns, L.stream_ptr()), "gemm_slices_f32")
     ref = torch.bmm(A.double(), Bm.double().transpose(1, 2))
     assert ((Cm.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+
+
+@pytest.mark.parametrize("T_,K,N,ns", [(2048, 256, 256, 36), (200, 64, 64, 5), (961, 128, 192, 7), (130, 32, 128, 3)])
+@pytest.mark.parametrize("scale", ["unit", "wide"])
+def test_gemm_slices_x3_is_fp32_accurate(L, T_, K, N, ns, scale):
+    """aclgan_gemm_slices_x3 (csrc/gemm_bf16x3.hip: fp32 operands split exactly into three bf16 numbers, six bf16 x bf16 products per
+    multiply accumulated in fp32 on the bf16 matrix cores) against a float64 bmm: the error must be that of fp32 arithmetic -- the
+    same bound as the fp32 MFMA kernel above, and no worse than 2x that kernel's own error on the same data -- NOT that of a bf16 GEMM
+    (4e-3).  `wide`: operand magnitudes spread over 12 decades row by row (the split is relative to each element: bf16 keeps fp32's
+    exponent range)."""
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(ns, T_, K, generator=g); Bm = torch.randn(ns, N, K, generator=g)
+    if scale == "wide":
+        A = A * (10.0 ** torch.randint(-6, 7, (ns, T_, 1), generator=g).float())
+        Bm = Bm * (10.0 ** torch.randint(-6, 7, (ns, N, 1), generator=g).float())
+    A, Bm = A.cuda(), Bm.cuda()
+    ref = torch.bmm(A.double(), Bm.double().transpose(1, 2))
+    # error scale of an fp32 dot product: |a| . |b| per output element
+    mag = torch.bmm(A.double().abs(), Bm.double().abs().transpose(1, 2)).clamp_min(1e-300)
+    C3 = torch.full((ns, T_, N), float("nan"), device="cuda")
+    scr = torch.empty(L.lib.aclgan_gemm_slices_x3_scratch_bytes(T_, K, N, ns) // 4 + 64, device="cuda")
+    L.check(L.lib.aclgan_gemm_slices_x3(L.ptr(A), L.ptr(Bm), L.ptr(C3), T_, K, N, ns, L.ptr(scr), L.stream_ptr()), "gemm_slices_x3")
+    C1 = torch.full((ns, T_, N), float("nan"), device="cuda")
+    L.check(L.lib.aclgan_gemm_slices_f32(L.ptr(A), L.ptr(Bm), L.ptr(C1), T_, K, N, ns, L.stream_ptr()), "gemm_slices_f32")
+    e3 = ((C3.double() - ref).abs() / mag).max().item()
+    e1 = ((C1.double() - ref).abs() / mag).max().item()
+    print("gemm_slices x3 vs f32 (T=%d K=%d N=%d, %s): componentwise rel err %.3g vs %.3g (fp32 eps 6e-8)" % (T_, K, N, scale, e3, e1))
+    assert e3 <= 5e-7                          # a handful of fp32 roundings (eps 6e-8); a bf16 product would be ~4e-3
+    assert e3 <= 2.0 * e1 + 1e-7
+    if scale == "unit":
+        assert ((C3.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+    C3b = torch.empty_like(C3)
+    L.check(L.lib.aclgan_gemm_slices_x3(L.ptr(A), L.ptr(Bm), L.ptr(C3b), T_, K, N, ns, L.ptr(scr), L.stream_ptr()))
+    assert torch.equal(C3, C3b)
