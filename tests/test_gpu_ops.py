@@ -79,6 +79,44 @@ def test_conv_fwd(L, case):
         assert torch.equal(y, y2)
 
 
+WINO_X3_CASES = [CONV_CASES[3], CONV_CASES[4], CONV_CASES[5], CONV_CASES[6], CONV_CASES[8], CONV_CASES[9],
+                 (2, 32, 32, 128, 128, 3, 1, 1, 0, "relu"), (1, 20, 24, 64, 192, 3, 1, 1, 0, "none")]
+
+
+@pytest.mark.parametrize("case", WINO_X3_CASES)
+def test_winograd_with_split_bf16_gemm_slices(L, case):
+    """The option aclgan_set_tuning("wino_x3", 1) (csrc/gemm_bf16x3.hip: the GEMM slices of the fp32 Winograd pipeline as six bf16 x bf16
+    products per multiply, operands split exactly into three bf16 planes by the transforms) is fp32 arithmetic: forward and input
+    gradient agree with the oracle to the same tolerance as the fp32 MFMA slices, and with the fp32-slices result itself to fp32 rounding."""
+    from gpu_util import conv_desc, gpu_conv_fwd, gpu_conv_dgrad, nhwc, nchw, ohwi, rel_err
+    B, Hi, Wi, Ci, Co, k, s, p, up, act = case
+    x, w, b = _case_tensors(case, 3)
+    x.requires_grad_(True)
+    ref = O.conv_block(x, w, b, s, p, act, upsample=bool(up))
+    y_lin = O.conv_block(x, w, b, s, p, "none", upsample=bool(up))
+    dy = torch.randn(y_lin.shape, generator=torch.Generator().manual_seed(5))
+    y_lin.backward(dy)
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, act)
+    dn = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, "none")
+    xg, wg, bg, dyg = nhwc(x.detach()).cuda(), ohwi(w).cuda(), b.cuda(), nhwc(dy).cuda()
+    out = {}
+    old = L.lib.aclgan_set_tuning(b"wino_x3", 0)
+    try:
+        for v in (0, 1):
+            L.lib.aclgan_set_tuning(b"wino_x3", v)
+            out[v] = (gpu_conv_fwd(L, d, xg, wg, bg), gpu_conv_dgrad(L, dn, dyg, wg))
+    finally:
+        L.lib.aclgan_set_tuning(b"wino_x3", old)
+    for v in (0, 1):
+        assert rel_err(nchw(out[v][0]), ref) < TOL
+        assert rel_err(nchw(out[v][1]), x.grad) < TOL
+    # the two GEMM implementations differ by fp32 rounding only (the transforms amplify it by the same ~1.5 digits either way)
+    assert rel_err(out[1][0], out[0][0]) < 2e-5 and rel_err(out[1][1], out[0][1]) < 2e-5
+    # and with both against the fp64 truth the split-bf16 result is no worse than 1.5x the fp32 MFMA one
+    e0, e1 = rel_err(nchw(out[0][0]), ref.double()), rel_err(nchw(out[1][0]), ref.double())
+    assert e1 <= 1.5 * e0 + 1e-6, (e0, e1)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(L, case):
     from gpu_util import conv_desc, gpu_conv_dgrad, nhwc, nchw, ohwi, rel_err
