@@ -229,9 +229,12 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 // sum = 0: y through view ph  (+)= act((A^T M_ph A) + bias), one view per phase (forward: the phases interleave into the hi-res map);
 // sum = 1: y through view 0   (+)= sum over the nph phases of A^T M_ph A  (dgrad: all phases land on the same low-res dx).
 // Outputs beyond the view's logical extent (ragged last tiles) are dropped.
-template <int NV>
+// (SUM as a template parameter: the forward variant then carries neither the 4 x 4 accumulator tile nor the phase loop state -- fewer
+//  registers, one more wave per SIMD for a kernel that lives on memory-level parallelism)
+template <int NV, int SUM>
 __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y, int B, WViews vs,
-                                                          int C, int TY, int TX, int act, int accumulate, int sum, float2* __restrict__ stats) {
+                                                          int C, int TY, int TX, int act, int accumulate, float2* __restrict__ stats) {
+    constexpr int sum = SUM;
     typedef typename VecOf<NV>::T F;
     const int Cv = C / NV;
     const int64_t T = (int64_t)B * TY * TX, n = T * Cv;
@@ -240,12 +243,14 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
         const int64_t t = i / Cv;
         const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((int64_t)TX * TY));
         const F bv = bias ? *reinterpret_cast<const F*>(bias + c) : (F)(0.f);
-        F tot[4][4];
+        F tot[SUM ? 4 : 1][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < (SUM ? 4 : 1); ++r)
 #pragma unroll
             for (int j = 0; j < 4; ++j) tot[r][j] = (F)(0.f);
         F st_sh = (F)(0.f), st_s = (F)(0.f), st_q = (F)(0.f);      // normalisation statistics of this tile (stats != nullptr), shifted sums
+        const unsigned int toff = (unsigned int)t * (unsigned int)C + (unsigned int)c;      // (T * C < 2^30: checked by the launcher) -- the 36
+        // plane addresses are then SGPR base + this one VGPR instead of 36 64-bit VGPR pairs (203 -> fewer registers, a third wave per SIMD)
         for (int ph = 0; ph < vs.nph; ++ph) {
             const float* Mp = M + (size_t)ph * 36 * T * C;
             F tmp[4][6];
@@ -253,7 +258,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
             for (int j = 0; j < 6; ++j) {              // columns: A^T M
                 F m[6];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const F*>(Mp + ((size_t)(r * 6 + j) * T + t) * C + c);
+                for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const F*>(Mp + (size_t)(r * 6 + j) * T * C + toff);      // uniform plane base + one 32-bit lane offset
                 F o[4];
                 at4(m, o);
 #pragma unroll
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                 at4(tmp[r], o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (sum) tot[r][j] += o[j];
+                    if (sum) tot[SUM ? r : 0][j] += o[j];
                     else {
                         const WView v = vs.v[ph];
                         const int oy = 4 * ty + r, ox = 4 * tx + j;
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                     const int oy = 4 * ty + r, ox = 4 * tx + j;
                     if (oy < v.H && ox < v.W) {
                         F* dst = reinterpret_cast<F*>(y + vaddr(v, b, oy, ox, C) + c);
-                        const F val = actv<NV>(tot[r][j] + bv, act);
+                        const F val = actv<NV>(tot[SUM ? r : 0][j] + bv, act);
                         *dst = accumulate ? *dst + val : val;
                     }
                 }
@@ -480,10 +485,17 @@ int launch_wino_input(const float* x, float* V, int B, const WViews& vs, int nph
 int launch_wino_output(const float* M, const float* bias, float* y, int B, const WViews& vs, int C, int TY, int TX, int act, int accumulate, int sum,
                        hipStream_t st, float2* stats = nullptr) {
     const int nv = wino_vec();
+    ACL_REQUIRE((int64_t)B * TY * TX * C < (1ll << 30), "wino_output: plane beyond 2^30 elements");
     const dim3 grid(grid_for((int64_t)B * TY * TX * (C / nv), 16384));
-    if (nv == 4) hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, sum, stats);
-    else if (nv == 2) hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, sum, stats);
-    else hipLaunchKernelGGL(wino_output_kernel<1>, grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, sum, stats);
+#define ACL_WO(NV_)                                                                                                                                     \
+    do {                                                                                                                                                \
+        if (sum) hipLaunchKernelGGL((wino_output_kernel<NV_, 1>), grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, stats);           \
+        else hipLaunchKernelGGL((wino_output_kernel<NV_, 0>), grid, dim3(256), 0, st, M, bias, y, B, vs, C, TY, TX, act, accumulate, stats);             \
+    } while (0)
+    if (nv == 4) ACL_WO(4);
+    else if (nv == 2) ACL_WO(2);
+    else ACL_WO(1);
+#undef ACL_WO
     ACL_CHECK_LAUNCH("wino_output_kernel");
     return ACLGAN_OK;
 }

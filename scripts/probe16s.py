@@ -18,7 +18,8 @@ def timed(fn, reps=20):
 
 
 for (B, H, Ci, Co, k, s, p, tag) in [(8, 64, 256, 256, 3, 1, 1, "ResBlock"), (8, 128, 128, 256, 4, 2, 1, "CE2"), (24, 128, 64, 128, 4, 2, 1, "D2 (3B joint)"),
-                                     (32, 64, 256, 256, 3, 1, 1, "ResBlock B=32")]:
+                                     (32, 64, 256, 256, 3, 1, 1, "ResBlock B=32"), (24, 64, 128, 256, 4, 2, 1, "D3 scale0"), (24, 32, 256, 512, 4, 2, 1, "D4 scale0"),
+                                     (24, 32, 128, 256, 4, 2, 1, "D3 scale1"), (24, 16, 256, 512, 4, 2, 1, "D4 scale1"), (8, 32, 256, 256, 3, 1, 1, "ResBlock 128px input")]:
     if os.environ.get("PROBE_ONLY") and os.environ["PROBE_ONLY"] != tag: continue
     Ho = (H + 2 * p - k) // s + 1
     d = L.ConvDesc(B, H, H, Ci, Co, k, s, p, 0, 0)
