@@ -382,7 +382,14 @@ class aclgan_Trainer:
             L.check(L.lib.aclgan_workspace_bytes(self._ctx, B, H, W, C.byref(need)), "workspace_bytes")
         if self._ws is None or self._ws.numel() < need.value:
             self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            try:
+                self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            except torch.OutOfMemoryError:
+                # arenas of trainers that are garbage but not yet collected (reference cycles through the bucket callbacks), and blocks
+                # the caching allocator keeps reserved: release both and try once more before giving up
+                import gc
+                gc.collect(); torch.cuda.empty_cache()
+                self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         L.check(L.lib.aclgan_bind_workspace(self._ctx, L.ptr(self._ws), self._ws.numel()), "bind_workspace")
         self._ws_shape = key + (not forward_only,)
 

@@ -17,3 +17,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_memory_between_tests(request):
+    """A training arena is tens of GB (52 GiB at 512x512 B=4); trainers of finished tests are garbage but sit in reference cycles and in
+    the caching allocator's reserve until someone collects them.  Without this the suite ran the 288 GB card out of memory near its end
+    (profiles/r03_gpu_tests.log, round 3)."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+        except Exception:
+            pass
