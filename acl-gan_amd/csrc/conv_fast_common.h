@@ -362,8 +362,21 @@ __global__ void wgrad_finish_kernel(WgFP p, WgPartX xp, int BM, int BN, int spli
         const int rw = (ml & 3) * MQ + (ml >> 2), q = nl >> 2;
         const int tile = tm * p.tiles_n + tn;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < splits; ++z) {
-            const float* pt = xp.part + (((size_t)z * xp.ny + phase) * p.nwg + tile) * ((size_t)BM * BN) + (size_t)rw * BN + q;
+        const float* p0 = xp.part + ((size_t)phase * p.nwg + tile) * ((size_t)BM * BN) + (size_t)rw * BN + q;
+        const size_t zs = (size_t)xp.ny * p.nwg * ((size_t)BM * BN);
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {       // the loads of four slices in flight, added in slice order (one dependent round trip per slice otherwise)
+            float a[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* pt = p0 + (size_t)(z + u) * zs;
+                a[u][0] = pt[0]; a[u][1] = pt[NQ]; a[u][2] = pt[2 * NQ]; a[u][3] = pt[3 * NQ];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s[0] += a[u][0]; s[1] += a[u][1]; s[2] += a[u][2]; s[3] += a[u][3]; }
+        }
+        for (; z < splits; ++z) {
+            const float* pt = p0 + (size_t)z * zs;
             s[0] += pt[0]; s[1] += pt[NQ]; s[2] += pt[2 * NQ]; s[3] += pt[3 * NQ];
         }
         f32x4* o = reinterpret_cast<f32x4*>(p.dw + ((size_t)phase * p.Co + m) * p.Kn + n4 * 4);

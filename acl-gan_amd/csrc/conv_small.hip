@@ -445,7 +445,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_thin_reduce_kernel(const float
     const int tap = blockIdx.x, l = threadIdx.x >> 2, v = threadIdx.x & 3;
     const int w0 = blockIdx.y * per_group, w1 = min(nwg, w0 + per_group);
     float s = 0.f;
-    for (int w = w0; w < w1; ++w) s += partial[((size_t)w * K * K + tap) * 256 + threadIdx.x];
+    const float* pp = partial + (size_t)tap * 256 + threadIdx.x;
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {           // eight loads in flight, added in workgroup order (one dependent round trip per partial otherwise)
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = pp[(size_t)(w + q) * (K * K * 256)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += a[q];
+    }
+    for (; w < w1; ++w) s += pp[(size_t)w * (K * K * 256)];
     if (gpart) { gpart[((size_t)blockIdx.y * K * K + tap) * 256 + threadIdx.x] = s; return; }
     const int widec = 4 * (l >> 2) + v, thin = l & 3;
     if (thin < CN) {
