@@ -141,6 +141,7 @@ bool conv16s_ok(const ConvGeom& g, int which);
 // stats (optional, conv_fwd16s_stats_chunk(g) > 0): [B][Ho*Wo / chunk][Co] (mean, M2) pairs of the STORED outputs -- norm_fwd's chunk partials
 int conv_fwd16s_stats_chunk(const ConvGeom& g);
 int set_glds_tile(int v);
+int set_dgrad16s_direct(int v);
 int set_wino_x3(int v);
 // gemm_bf16x3.hip: fp32-accurate GEMM slices on the bf16 matrix cores from 3-plane (h, m, l) bf16 operands
 bool gemm_x3_shape_ok(int T, int K, int N);

@@ -856,6 +856,14 @@ bool enabled() {
 // ------------------------------------------------------------------------------------------
 // which: 0 forward, 1 dgrad.  The forward also wants a grid that fills the chip without split-K (small late-discriminator maps keep the
 // split-K kernel of conv_fast16.hip, which reads the same 16-bit activations through its A16 path).
+// tuning / test knob behind aclgan_set_tuning("dgrad16s_direct", v); returns the previous value
+static int g_dgrad_direct = -1;
+int set_dgrad16s_direct(int v) {
+    if (g_dgrad_direct < 0) { const char* e = getenv("ACLGAN_DGRAD16S_DIRECT"); g_dgrad_direct = e ? (atoi(e) ? 1 : 0) : 0; }
+    const int old = g_dgrad_direct;
+    g_dgrad_direct = v ? 1 : 0;
+    return old;
+}
 // tuning / test knob behind aclgan_set_tuning("glds_tile", v): same values as ACLGAN_GLDS_TILE; returns the previous value
 int set_glds_tile(int v) {
     if (g_tile_force < 0) glds_tile(1, 1);
@@ -913,7 +921,7 @@ int conv_dgrad16s(const ConvGeom& g, int dtype, const void* dy16, const void* w1
     // direct mode (ACLGAN_DGRAD16S_DIRECT=1): pixels without mirrored partners skip the scratch round trip, the fold touches the border band
     // only.  Bit-identical results (197 operator / step / determinism tests pass with it on) and no measurable gain: bf16 step 55.2 vs 55.2 ms,
     // fp16 B=32 184.1 vs 185.6 (same box, back to back) -- the fold was not on the critical path.  Off by default.
-    static int direct_on = -1;
+    int& direct_on = g_dgrad_direct;
     if (direct_on < 0) { const char* e = getenv("ACLGAN_DGRAD16S_DIRECT"); direct_on = e ? (atoi(e) ? 1 : 0) : 0; }
     p.dx = dx; p.Hi = g.Hi; p.Wi = g.Wi; p.pad = g.p; p.accumulate = accumulate;
     p.direct = (direct_on && dxst == dtype && g.Ci % 2 == 0) ? 1 : 0;

@@ -291,6 +291,8 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
  * csrc/conv_glds16.hip).  key "glds_tile": 0 / 1 = 128-row tiles (default), 2 = 256 x 128, 3 = 256 x 256 where the shape allows, 4 = the
  * largest tile that still fills the chip.  key "wino_x3": 1 = the GEMM slices of the fp32 Winograd pipeline run as split-bf16
  * products on the bf16 matrix cores (fp32-accurate, see aclgan_gemm_slices_x3), 0 (default) = on the fp32 MFMA kernel.
+ * key "dgrad16s_direct": 1 = aclgan_conv2d_dgrad16s stores pixels without mirrored partners straight into a 16-bit dx (bit-identical,
+ * measured neutral), 0 (default) = every pixel through the padded scratch and the ordered fold.
  * Returns the previous value, -1 for an unknown key.  Not thread-safe against running launches. */
 int aclgan_set_tuning(const char* key, int value);
 /* The same launch with the normalisation statistics taken from its epilogue (round 3; replaces the norm_stats pass over y that

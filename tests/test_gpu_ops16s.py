@@ -164,9 +164,19 @@ def test_conv_fwd16s_epilogue_statistics(L, case, dt, yst, tile):
     assert torch.equal(stats, s2)
 
 
+@pytest.fixture(params=[0, 1], ids=["fold", "direct"])
+def direct(request, L):
+    """1: pixels without mirrored partners are written by the GEMM epilogue straight into a 16-bit dx (csrc/conv_glds16.hip store_acc_dx),
+    the fold touches the border band only -- the same bits as the full fold (default), which the assertions below pin"""
+    old = L.lib.aclgan_set_tuning(b"dgrad16s_direct", request.param)
+    assert old >= 0
+    yield request.param
+    L.lib.aclgan_set_tuning(b"dgrad16s_direct", old)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_dgrad16s(L, case, dt, tile):
+def test_conv_dgrad16s(L, case, dt, tile, direct):
     from gpu_util import conv_desc, nhwc, nchw, ohwi
     B, Hi, Wi, Ci, Co, k, s, p, act = case
     d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, 0, "none")
