@@ -37,14 +37,14 @@ pytestmark = pytest.mark.gpu
 FTOL = {"bf16": 6e-2, "fp16": 8e-3}
 LTOL = {"bf16": 1e-3, "fp16": 1e-4}         # adversarial / identity / total losses (measured worst 2.1e-4 / 1.5e-5)
 LTOL_DIGIT = {"bf16": 1.5e-2, "fp16": 1.2e-3}   # sum 1/(|m-.5|+0.01): ill-conditioned in the mask values (measured over the round-3 builds: up to 8.5e-3 / 6.3e-4)
-LTOL_SIZE = {"bf16": 6e-2, "fp16": 1.5e-2}    # relu(sum(m - upper))^2 near its threshold (measured 3.2e-2 / 8.1e-3)
+LTOL_SIZE = {"bf16": 1e-1, "fp16": 1.5e-2}    # relu(sum(m - upper))^2 near its threshold: a difference of two large sums, squared (measured over the round-3 builds: up to 4.8e-2 / 8.1e-3)
 GTOL = {"bf16": 3e-1, "fp16": 1.2e-1}
 # vs the emulated contract.  The deepest tensor (x_A2_fake: encode -> decode -> encode -> decode, ~60 roundings deep) is chaotic in the
 # LAST BIT of anything upstream: between two builds of this round that differ only in the association order of the epilogue statistics it
 # measured 3.9e-2 .. 5.6e-2 (bf16) and 4.9e-3 .. 6.4e-3 (fp16); the shallow tensors (c_1 8e-3, s_2 below, discriminator outputs 4e-3) are stable
 ETOL_F = {"bf16": 8e-2, "fp16": 1e-2}
 ETOL_S2 = {"bf16": 5e-4, "fp16": 2e-4}     # the shallow tensor s_2 vs the emulated contract (measured 1.3e-4 / 1.05e-4 with 16-bit storage: the pool averages rounded values)
-ETOL_G = {"bf16": 2.5e-1, "fp16": 1e-1}    # measured worst 1.67e-1 / 6.3e-2
+ETOL_G = {"bf16": 2.5e-1, "fp16": 1e-1}    # measured worst 2.08e-1 / 7.75e-2 with 16-bit activation / gradient storage (stable to 3 digits over five builds)
 SCALE = {"bf16": 1.0, "fp16": 65536.0}
 
 
