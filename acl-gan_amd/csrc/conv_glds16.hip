@@ -46,7 +46,7 @@ struct QFP16 {
 };
 
 constexpr int ROWB = 128;          // bytes per LDS row = 64 halfs = one k-tile
-constexpr int OOB = 0x7ffffff0;    // voffset of a DMA lane that must read zero (beyond any num_records)
+[[maybe_unused]] constexpr int OOB = 0x7ffffff0;    // voffset of a DMA lane that must read zero (beyond any num_records)
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 

@@ -50,7 +50,7 @@ struct G3P {
     int T, K, N, nslices, a_mod, tiles_m, tiles_n, nwg;
 };
 
-constexpr int R3 = 64;               // bytes per LDS row = 32 bf16 = one k-tile of one plane
+[[maybe_unused]] constexpr int R3 = 64;               // bytes per LDS row = 32 bf16 = one k-tile of one plane
 
 // PERSISTENT: the grid is one workgroup per CU; workgroup w walks the output tiles xcd_map(w + i gridDim.x) (same XCD every time, a
 // contiguous chunk of the slice-major tile order per XCD: the tiles of a slice share its U planes in that XCD's L2).  The k-tiles of
