@@ -143,6 +143,13 @@ int conv_fwd16s_stats_chunk(const ConvGeom& g);
 int set_glds_tile(int v);
 int set_dgrad16s_direct(int v);
 int set_wino_x3(int v);
+// conv_wino_fused.hip (round 4): Winograd F(4x4,3x3) as ONE launch -- input transform, 36 frequency GEMMs, output transform
+int wino_fused_mode();                           // 0 off, 1 fused
+int set_wino_fused(int v);                       // returns the previous mode
+bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act = ACLGAN_ACT_NONE);
+int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st);
+int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* Uf, const float* bias, float* out, int act, int accumulate,
+                      int reflect, float2* stats, hipStream_t st);
 // gemm_bf16x3.hip: fp32-accurate GEMM slices on the bf16 matrix cores from 3-plane (h, m, l) bf16 operands
 bool gemm_x3_shape_ok(int T, int K, int N);
 int gemm_slices_x3(const void* A3, size_t a_plane, const void* B3, size_t b_plane, float* C, int T, int K, int N, int nslices, int a_mod, hipStream_t st);

@@ -565,6 +565,12 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
     const int TY = H / 4, TX = W / 4;
     const int64_t T = (int64_t)B * TY * TX;
     char* cur = (char*)scratch;
+    if (!keepV && wino_fused_ok(B, H, W, Cin_, Cout_, act)) {      // one launch (conv_wino_fused.hip): neither V nor M exists in memory
+        bool fresh_f = true;
+        float* Uf = cached_u((float*)scratch, w, flip ? 1 : 0, (size_t)36 * Cout_ * Cin_ * 4, &fresh_f);
+        if (fresh_f) { const int rcf = wino_fused_filter(w, Uf, w_co, w_ci, flip, st); if (rcf) return rcf; }
+        return wino_fused_launch(B, H, W, Cin_, Cout_, in, Uf, bias, out, act, accumulate, reflect, stats, st);
+    }
     const bool x3 = !keepV && wino_x3() && gemm_x3_shape_ok((int)T, Cin_, Cout_);      // (a kept V feeds the fp32 weight-gradient GEMM: fp32)
     const size_t eb = x3 ? 6 : 4;
     float* U = take(cur, (size_t)36 * Cout_ * Cin_ * 6);
@@ -592,6 +598,7 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
 size_t conv_wino_keep_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     if (wino_x3() && gemm_x3_shape_ok(1, g.Ci, g.Co)) return 0;      // the forward writes V as bf16 planes; the fp32 weight-gradient GEMM transforms x itself
+    if (wino_fused_ok(g.B, g.Hi, g.Wi, g.Ci, g.Co, g.act)) return 0;         // the fused forward never materialises V
     return align256((size_t)36 * g.B * (g.Ho / 4) * (g.Wo / 4) * g.Ci * sizeof(float));
 }
 int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats, float* keepV) {

@@ -1,0 +1,464 @@
+// conv_wino_fused.hip -- Winograd F(4x4, 3x3) as ONE launch (round 4): input transform, the 36 frequency GEMMs and the output
+// transform in a single kernel, so neither V = B^T d B nor M = U (.) V ever exists in HBM (conv_wino.hip: three launches and
+// 2 x 75.5 MB of plane traffic per ResBlock convolution -- 90 GB of the 299 GB the fp32 step moved in round 3).
+// Replaces ReflectionPad2d(1) + Conv2d(3x3) of the ResBlocks (networks.py:297-310, 366-370) forward, and -- with zero padding and
+// the flipped / transposed filter -- the interior of their input gradient.
+//
+// Work decomposition (fp32, v_mfma_f32_32x32x2_f32):
+//   workgroup = 4 waves (one per SIMD, up to 512 registers each) = a block of 8 x 4 output tiles (32 x 16 pixels) x 64 output
+//               channels x ALL 36 frequencies; the K loop runs over the input channels.
+//   wave (wi, wj) of the 2 x 2 wave grid owns the 3 x 3 frequency block rows 3wi..3wi+2, columns 3wj..3wj+2 of the 6 x 6 Winograd
+//               domain: 9 frequencies x (32 tiles x 64 channels) = 18 accumulator tiles of 32 x 32 = 288 accumulator registers.
+//   A operand  = the transformed input.  The raw 18 x 34 pixel patch of the tile block is staged in LDS (KC channels at a time,
+//               double-buffered); every lane reads the 5 x 5 sub-patch its wave's frequency block needs for ITS tile (MFMA row =
+//               tile, lane half = channel pair) and transforms it in registers: the separable B^T d B restricted to 3 rows x 3
+//               columns costs 48 packed VALU operations per 36 MFMAs.  The transform output IS the MFMA A fragment: V never
+//               touches LDS.
+//   B operand  = U = G g G^T, written ONCE per update by wino_filter_frag_kernel in MFMA-fragment order: a wave's 18 B
+//               fragments of a 4-channel step are 18 contiguous 512-byte global loads straight into registers -- no LDS, no
+//               barrier, no redundancy between the waves (each owns different frequencies).
+//   epilogue   = the 36 frequency accumulators of a (tile, channel) pair live in four waves: exchanged through LDS (two passes
+//               of 144 KB), A^T M A + bias + activation per thread, 128-byte rows stored to y, and the (mean, M2) of each 4 x 4
+//               output tile = the chunk partials of the following normalisation layer.
+//
+// LDS patch layout: units of 8 bytes (one channel pair), unit(q, r, c) = (q * 18 + r) * 42 + (c & 3) * 9 + (c >> 2): the 32 lanes of
+// a ds_read_b64 group (8 tile columns x 4 tile rows) read units const + 168 * ty + tx = const + 8 ty + tx (mod 32): conflict-free.
+#include "common.h"
+#include <cstdlib>
+#include <algorithm>
+
+namespace aclgan {
+
+const WinoUCache* wino_ucache();
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TBX = 8, TBY = 4;                  // output tiles per workgroup block
+constexpr int PR = 4 * TBY + 2, PC = 4 * TBX + 2, NPIX = PR * PC;     // 18 x 34 input pixels
+constexpr int RS = 42;                           // row stride in 8-byte units (36 used); 4 * RS = 8 (mod 32)
+constexpr int QS = PR * RS;                      // units per channel-pair plane
+constexpr int NBC = 64;                          // output channels per workgroup
+constexpr unsigned int OOBV = 0x7ffffff0u;       // buffer offset that reads zero
+constexpr int M_BYTES = 36 * 32 * 32 * 4;        // epilogue exchange buffer (one 32-channel half)
+
+struct WfP {
+    const float* x; const float* Uf; const float* bias; float* y; float2* stats;
+    int B, H, W, Cin, Cout, TY, TX, NBY, NBX, off, reflect, act, accumulate, ncb, ntb, xcdmap;
+    long long xbytes, ubytes;
+};
+
+__device__ __forceinline__ int reflf(int v, int n) {
+    v = v < 0 ? -v : v;
+    return v >= n ? 2 * (n - 1) - v : v;
+}
+__device__ __forceinline__ float actf(float v, int act) {
+    if (act == ACLGAN_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACLGAN_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    if (act == ACLGAN_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ void at4f(const float (&m)[6], float (&y)[4]) {
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
+    y[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
+    y[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
+}
+__device__ __forceinline__ void g6f(const float (&g)[3], float (&u)[6]) {
+    u[0] = 0.25f * g[0];
+    u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
+    u[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
+    u[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    u[5] = g[2];
+}
+
+// U in fragment order: Uf[cb][kq][wave g][fi][j][lane][e]  (floats)
+//   row R (forward: cout, dgrad: cin) = cb * 64 + j * 32 + (lane & 31);  k (forward: cin, dgrad: cout) = kq * 4 + 2 * (lane >> 5) + e
+//   frequency (i, jf): wave g = (i / 3) * 2 + jf / 3, fi = (i % 3) * 3 + jf % 3
+__global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __restrict__ w, float* __restrict__ Uf, int Co, int Ci, int flip) {
+    const int R = flip ? Ci : Co, K = flip ? Co : Ci, KQ = K >> 2;
+    const int64_t n = (int64_t)R * K;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        // consecutive threads -> consecutive rows of one k (the 36 stores of a wave then fill 128-byte runs of the fragment layout)
+        const int row = (int)(idx % R), kk = (int)(idx / R);
+        const int co = flip ? kk : row, ci = flip ? row : kk;
+        float t[6][3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float c[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                c[ky] = w[((size_t)(co * 3 + sy) * 3 + sx) * Ci + ci];
+            }
+            float o[6];
+            g6f(c, o);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) t[a][kx] = o[a];
+        }
+        const int cb = row >> 6, j = (row >> 5) & 1, l31 = row & 31;
+        const int kq = kk >> 2, h = (kk >> 1) & 1, e = kk & 1;
+        float* base = Uf + ((size_t)cb * KQ + kq) * (4 * 9 * 2 * 128) + (size_t)j * 128 + (h * 32 + l31) * 2 + e;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float o[6];
+            g6f(t[a], o);
+#pragma unroll
+            for (int jf = 0; jf < 6; ++jf) {
+                const int g = (a / 3) * 2 + jf / 3, fi = (a % 3) * 3 + jf % 3;
+                base[(size_t)(g * 9 + fi) * 256] = o[jf];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ f32x2 opaque2(float v) {      // a constant pair the compiler cannot fold: keeps the transform in v_pk_* form
+    f32x2 r = {v, v};
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+struct BtK { f32x2 k4, k5n, k4n, k2, k2n; };
+// three rows of B^T d: W = 0: rows 0, 1, 2 from d0..d4;  W = 1: rows 3, 4, 5 from d1..d5  (x = the five inputs that set needs): 6 packed operations
+template <int W>
+__device__ __forceinline__ void bt3(const BtK& k, const f32x2 (&x)[5], f32x2& o0, f32x2& o1, f32x2& o2) {
+    if (W == 0) {
+        const f32x2 pp = fma2(k.k4n, x[2], x[4]), qq = fma2(k.k4, x[1], -x[3]);
+        o0 = fma2(k.k4, x[0], fma2(k.k5n, x[2], x[4]));
+        o1 = pp - qq;
+        o2 = pp + qq;
+    } else {
+        const f32x2 pp = x[3] - x[1], sd = x[2] - x[0];
+        o0 = fma2(k.k2, sd, pp);
+        o1 = fma2(k.k2n, sd, pp);
+        o2 = fma2(k.k4, x[0], fma2(k.k5n, x[2], x[4]));
+    }
+}
+
+constexpr int KC = 8;                            // input channels per staged chunk (two 4-channel MFMA sub-steps)
+constexpr int NP = 5;                            // 16-byte staging pieces per thread and chunk (612 pixels x 2 pieces <= 5 x 256)
+constexpr int XBUF = (KC / 2) * QS;              // 8-byte units per patch buffer
+constexpr int UD = 8;                            // U fragments are loaded UD slices ahead of their MFMAs
+
+// One wave's share of the K loop.  WI, WJ: the wave's frequency block.
+// MEASURED (scripts/microbench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 runs on the fp32 VALU lanes -- a VALU instruction of the same
+// SIMD never hides behind it (each costs its 4 cycles on top of the 64 of an MFMA, plus ~20 cycles per MFMA -> VALU -> MFMA round trip),
+// while LDS and memory instructions do.  So the loop body keeps the VALU out of the MFMA stream: addresses are SGPR bases + constant lane
+// offsets + immediates (buffer loads, static LDS buffer parity through a 2x unrolled chunk loop), the transform is written in packed
+// form (48 v_pk_* per sub-step) and issued as ONE burst per sub-step.
+template <int WI, int WJ, int ABL>
+__device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane, const int cb, const unsigned int (&go)[NP], const int (&lub)[NP],
+                                        f32x16 (&acc)[9][2]) {
+    const int nch = p.Cin / KC, KQ = p.Cin >> 2;
+    const int wave = WI * 2 + WJ;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int lanebase = (h * QS + 4 * (l31 >> 3) * RS + (l31 & 7)) * 8;      // bytes
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Uf), 0, (int)p.ubytes, 0x00020000);
+    const int uvo = lane * 8;                                                  // lane part of a U fragment address
+    const int ustep = 4 * 9 * 2 * 64 * 8;                                      // bytes of one 4-channel step of a channel block
+    const int ubase = (cb * KQ * 4 + wave) * (9 * 2 * 64 * 8);
+    const BtK bk = {opaque2(4.f), opaque2(-5.f), opaque2(-4.f), opaque2(2.f), opaque2(-2.f)};
+
+    // ---- staging of the raw patch: piece i of a chunk is issued at window slice 3i and written to LDS at slice 3i + 5 ----
+    f32x4 xr[2];
+    auto xissue = [&](int chunk, int i) __attribute__((always_inline)) {
+        xr[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], min(chunk, nch - 1) * KC * 4, 0));
+    };
+    auto xwrite = [&](int par, int i) __attribute__((always_inline)) {       // par: parity of the chunk = its LDS buffer (compile time)
+        char* dst = smem + par * XBUF * 8 + lub[i];
+        *reinterpret_cast<f32x2*>(dst) = (f32x2){xr[i & 1].x, xr[i & 1].y};
+        *reinterpret_cast<f32x2*>(dst + QS * 8) = (f32x2){xr[i & 1].z, xr[i & 1].w};
+    };
+    auto xslot = [&](int chunk, int par, int wsl) __attribute__((always_inline)) {
+        if (wsl >= 5 && (wsl - 5) % 3 == 0 && (wsl - 5) / 3 < NP) xwrite(par, (wsl - 5) / 3);
+        if (wsl % 3 == 0 && wsl / 3 < NP) xissue(chunk, wsl / 3);
+    };
+
+    f32x2 u[9][2];
+    auto uload = [&](int kq, int fi) __attribute__((always_inline)) {
+        const int so = ubase + min(kq, KQ - 1) * ustep;                         // scalar
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = fi * 2 + j;
+            u[fi][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ru, uvo + (idx & 7) * 512, so + (idx >> 3) * 4096, 0));
+        }
+    };
+    // the wave's 5 x 5 sub-patch of one sub-step (read from LDS well ahead of the burst that transforms it)
+    f32x2 d[5][5];      // [column][row]
+    auto rdcol = [&](int par, int ss, int c) __attribute__((always_inline)) {
+        const int cc = WJ + c;
+        const char* src = smem + par * XBUF * 8 + lanebase;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) d[c][r] = *reinterpret_cast<const f32x2*>(src + (2 * ss * QS + (WI + r) * RS + (cc & 3) * 9 + (cc >> 2)) * 8);
+    };
+    auto transform = [&](f32x2 (&V)[9]) __attribute__((always_inline)) {      // 48 packed operations
+        f32x2 t[3][5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) bt3<WI>(bk, d[c], t[0][c], t[1][c], t[2][c]);
+#pragma unroll
+        for (int il = 0; il < 3; ++il) bt3<WJ>(bk, t[il], V[il * 3], V[il * 3 + 1], V[il * 3 + 2]);
+    };
+    // 18 accumulator tiles = 288 registers: 16 tiles fill the 256 AGPRs; the MFMAs of the last two (fi = 8) are written in their VGPR
+    // form by hand (the builtin would take the AGPR form for every tile and shuttle tiles between the two files on every iteration)
+    auto mfma1 = [&](int fi, int j, float a, float b) __attribute__((always_inline)) {
+        if (fi == 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[fi][j]) : "v"(a), "v"(b));
+        else acc[fi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[fi][j], 0, 0, 0);
+    };
+
+    // ---- prologue: chunk 0 in LDS, the first window slices of chunk 1 done, the first U fragments in flight, V of sub-step 0 computed ----
+    {   // every load of the prologue is issued before the first one is waited for
+        f32x4 xp[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) xp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], 0, 0));
+        xissue(1, 0);
+        xissue(1, 1);
+#pragma unroll
+        for (int fi = 0; fi < UD; ++fi) uload(0, fi);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            *reinterpret_cast<f32x2*>(smem + lub[i]) = (f32x2){xp[i].x, xp[i].y};
+            *reinterpret_cast<f32x2*>(smem + lub[i] + QS * 8) = (f32x2){xp[i].z, xp[i].w};
+        }
+        // = the state after window slices 0 .. 8 of chunk 1: pieces 0, 1 written, piece 2 in flight
+        xwrite(1, 0);
+        xissue(1, 2);
+        xwrite(1, 1);
+    }
+    __syncthreads();
+    f32x2 Va[9], Vb[9];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) rdcol(0, 0, c);
+    transform(Va);
+    if (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Vb[i] = Va[i];
+    }
+
+    // ---- main loop: sub-step (ch, ss) multiplies V(ch, ss) while the patch of the next sub-step is read, U(ch, ss + 1) is loaded and
+    // the chunk after next is staged; the transform of the next sub-step is ONE burst behind the last MFMA of the sub-step ----
+    auto substep = [&](int ch, int par, int ss, f32x2 (&Vc)[9], f32x2 (&Vn)[9]) __attribute__((always_inline)) {
+        const int kq = ch * 2 + ss;
+        const int npar = ss == 0 ? par : par ^ 1, ns = ss == 0 ? 1 : 0;      // buffer / sub-step index of the NEXT sub-step's patch
+        // staging window of chunk ch + 1: sub-steps (ch - 1, 1), (ch, 0); the last sub-step already stages ch + 2 (into this chunk's buffer)
+        const int schunk = ss == 1 ? ch + 2 : ch + 1, spar = ss == 1 ? par : par ^ 1;
+        const int wbase = ss == 1 ? 0 : 9;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            mfma1(s, 0, Vc[s].x, u[s][0].x);
+            mfma1(s, 1, Vc[s].x, u[s][1].x);
+            mfma1(s, 0, Vc[s].y, u[s][0].y);
+            mfma1(s, 1, Vc[s].y, u[s][1].y);
+            if (!(ABL & 2)) uload(s + UD < 9 ? kq : kq + 1, (s + UD) % 9);
+            if (s < 5 && !(ABL & 1)) rdcol(npar, ns, s);
+            if (!(ABL & 4)) xslot(schunk, spar, wbase + s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(ABL & 1)) transform(Vn);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ss == 0 && !(ABL & 8)) __syncthreads();
+    };
+    for (int ch = 0; ch < ((ABL & 16) ? 0 : nch); ch += 2) {
+        substep(ch, 0, 0, Va, Vb);
+        substep(ch, 0, 1, Vb, Va);
+        substep(ch + 1, 1, 0, Va, Vb);
+        substep(ch + 1, 1, 1, Vb, Va);
+    }
+}
+
+// ABL (measurement builds only): bit 0 drops the transforms, 1 the U loads, 2 the patch staging, 3 the barrier of the main loop
+template <int ABL = 0>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) wino_fused_kernel(WfP p) {
+    constexpr int JN = KC / 4;
+    constexpr int NSLOT = NPIX * JN;
+    constexpr int MAIN_BYTES = 2 * XBUF * 8;
+    __shared__ __attribute__((aligned(16))) char smem[MAIN_BYTES > M_BYTES ? MAIN_BYTES : M_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int cb, tb;
+    {
+        const int bid = blockIdx.x;
+        if (p.xcdmap) { const int per = 8 / p.ncb, xcd = bid & 7, idx = bid >> 3; cb = xcd / per; tb = idx * per + xcd % per; }
+        else { cb = bid % p.ncb; tb = bid / p.ncb; }
+    }
+    const int bx = tb % p.NBX, by = (tb / p.NBX) % p.NBY, b = tb / (p.NBX * p.NBY);
+    const int ty0 = by * TBY, tx0 = bx * TBX;
+    // (The workgroups of an XCD share one slice of U and walk K in lockstep.  MEASURED: starting every tile block at a different input
+    //  channel -- so that a U line is a first touch for one workgroup only -- is 25 % SLOWER: 128 against 103.5 us; lockstep is what
+    //  keeps the slice's lines hot in the XCD's L2.)
+
+    // gather offsets of this thread's staging pieces (the same for every chunk: only the channel offset moves): registers
+    unsigned int go[NP];
+    int lub[NP];                                          // LDS byte offset of the piece's first channel pair inside a patch buffer
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int s = i * 256 + tid;
+        go[i] = OOBV;
+        lub[i] = 36 * 8;                                  // padding unit of row 0: never read
+        if (s < NSLOT) {
+            const int pix = s / JN, j = s - pix * JN;
+            const int r = pix / PC, c = pix - r * PC;
+            int iy = 4 * ty0 + p.off + r, ix = 4 * tx0 + p.off + c;
+            if (p.reflect) { iy = reflf(iy, p.H); ix = reflf(ix, p.W); }
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                go[i] = (unsigned int)((((size_t)b * p.H + iy) * p.W + ix) * p.Cin * 4 + j * 16);
+            lub[i] = (2 * j * QS + r * RS + (c & 3) * 9 + (c >> 2)) * 8;
+        }
+    }
+
+    f32x16 acc[9][2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ABL & 512) p.y[tid] = 0.f;
+    if (wave == 0) wf_wave<0, 0, ABL>(p, smem, lane, cb, go, lub, acc);
+    else if (wave == 1) wf_wave<0, 1, ABL>(p, smem, lane, cb, go, lub, acc);
+    else if (wave == 2) wf_wave<1, 0, ABL>(p, smem, lane, cb, go, lub, acc);
+    else wf_wave<1, 1, ABL>(p, smem, lane, cb, go, lub, acc);
+
+    // ---- epilogue: exchange the frequency accumulators through LDS (two passes of 16 tiles x 64 channels x 36 frequencies = 144 KB),
+    // output transform with four channels per thread (ds_read_b128, 256-byte rows of y per 16 lanes), bias / activation / statistics ----
+    float* Ms = reinterpret_cast<float*>(smem);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tl = tid >> 4, c4 = tid & 15;
+    const int n = cb * NBC + c4 * 4;
+    const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4)(0.f);
+    const float slope = p.act == ACLGAN_ACT_RELU ? 0.f : (p.act == ACLGAN_ACT_LRELU ? 0.2f : 1.f);      // act(v) = max(v, 0) + slope * min(v, 0)
+#pragma unroll
+    for (int P = 0; P < ((ABL & 512) ? 0 : 2); ++P) {
+        __syncthreads();                          // the patch buffers / the previous half are no longer read
+#pragma unroll
+        for (int fi = 0; fi < 9; ++fi) {
+            const int f = (3 * wi + fi / 3) * 6 + 3 * wj + fi % 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int tr = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;      // tile of this half
+                    Ms[(f * 16 + tr) * 64 + j * 32 + l31] = acc[fi][j][8 * P + r8];
+                }
+        }
+        __syncthreads();
+        if (ABL & 256) continue;
+        const int tile = 16 * P + tl;
+        const int ty = ty0 + (tile >> 3), tx = tx0 + (tile & 7);
+        const bool live = ty < p.TY && tx < p.TX;
+        float* ybase = p.y + (((size_t)b * p.H + 4 * (live ? ty : 0)) * p.W + 4 * (live ? tx : 0)) * p.Cout + n;
+        f32x4 old[4][4];
+        if (p.accumulate) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) old[a][bb] = *reinterpret_cast<const f32x4*>(ybase + ((size_t)a * p.W + bb) * p.Cout);
+        }
+        f32x4 tmp[4][6];
+#pragma unroll
+        for (int jf = 0; jf < 6; ++jf) {
+            f32x4 m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(Ms + ((i * 6 + jf) * 16 + tl) * 64 + c4 * 4);
+            tmp[0][jf] = m[0] + m[1] + m[2] + m[3] + m[4];
+            tmp[1][jf] = m[1] - m[2] + 2.f * (m[3] - m[4]);
+            tmp[2][jf] = m[1] + m[2] + 4.f * (m[3] + m[4]);
+            tmp[3][jf] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
+        }
+        f32x4 sh = (f32x4)(0.f), s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 (&q)[6] = tmp[a];
+            f32x4 o[4];
+            o[0] = q[0] + q[1] + q[2] + q[3] + q[4];
+            o[1] = q[1] - q[2] + 2.f * (q[3] - q[4]);
+            o[2] = q[1] + q[2] + 4.f * (q[3] + q[4]);
+            o[3] = q[1] - q[2] + 8.f * (q[3] - q[4]) + q[5];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                f32x4 v = o[bb] + bv, val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = fmaxf(v[e], 0.f) + slope * fminf(v[e], 0.f);
+                if (p.accumulate) val += old[a][bb];
+                if (live && !(ABL & 128)) *reinterpret_cast<f32x4*>(ybase + ((size_t)a * p.W + bb) * p.Cout) = val;
+                if (a == 0 && bb == 0) sh = val;
+                const f32x4 dv = val - sh;
+                s1 += dv; s2 += dv * dv;
+            }
+        }
+        if (p.stats && live) {      // (mean, M2) of the tile's 16 outputs per channel: the chunk partials norm_finalize_* combines
+            const f32x4 mean = sh + s1 * (1.f / 16.f), m2 = s2 - s1 * s1 * (1.f / 16.f);
+            float* so = reinterpret_cast<float*>(p.stats + (((size_t)b * p.TY + ty) * p.TX + tx) * p.Cout + n);
+            *reinterpret_cast<f32x4*>(so) = (f32x4){mean[0], m2[0], mean[1], m2[1]};
+            *reinterpret_cast<f32x4*>(so + 4) = (f32x4){mean[2], m2[2], mean[3], m2[3]};
+        }
+    }
+}
+
+int g_wino_fused = -1;
+
+}  // namespace
+
+// tuning / test knob behind aclgan_set_tuning("wino_fused", v): 0 = the three-launch pipeline of conv_wino.hip, 1 = the fused kernel;
+// returns the previous value.  ACLGAN_WINO_FUSED sets the default.  (bits 4.. select a measurement build when compiled with
+// -DACLGAN_FUSED_ABLATION)
+int wino_fused_mode() {
+    if (g_wino_fused < 0) { const char* e = getenv("ACLGAN_WINO_FUSED"); g_wino_fused = e ? atoi(e) : 1; if (g_wino_fused < 0 || (g_wino_fused & 15) > 1) g_wino_fused = 1; }
+    return g_wino_fused;
+}
+int set_wino_fused(int v) { const int old = wino_fused_mode(); g_wino_fused = (v < 0 || (v & 15) > 1) ? 1 : v; return old; }
+
+// the fused kernel takes: K-side channels a multiple of the chunk, output channels a multiple of 64, byte offsets below 2^31
+bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act) {
+    const int m = wino_fused_mode() & 15;
+    if (m == 0) return false;
+    return act != ACLGAN_ACT_TANH && H % 4 == 0 && W % 4 == 0 && Cin_ % (2 * KC) == 0 && Cout_ % NBC == 0 && (long long)36 * Cin_ * Cout_ * 4 < 0x7fffffe0ll && H >= 4 && W >= 4 && (long long)B * H * W * Cin_ * 4 < 0x7fffffe0ll;
+}
+size_t wino_fused_u_bytes(int Cin_, int Cout_) { return (size_t)36 * Cin_ * Cout_ * sizeof(float); }
+
+// Uf <- fragment-ordered G g G^T of w (flip: the flipped, transposed filter of the input gradient)
+int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st) {
+    const int64_t n = (int64_t)Co * Ci;
+    hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, w, Uf, Co, Ci, flip);
+    ACL_CHECK_LAUNCH("wino_filter_frag_kernel");
+    return ACLGAN_OK;
+}
+
+// out[B][H][W][Cout_] (+)= act(conv3x3(in[B][H][W][Cin_]) + bias) with U already in fragment order; reflect: reflection padding 1,
+// else zero padding.  stats (optional): [B][H/4 * W/4][Cout_] (mean, M2) of the 4x4 output tiles.
+int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* Uf, const float* bias, float* out, int act, int accumulate,
+                      int reflect, float2* stats, hipStream_t st) {
+    if (!wino_fused_ok(B, H, W, Cin_, Cout_, act)) return ACLGAN_EUNSUPPORTED;
+    WfP p;
+    p.x = in; p.Uf = Uf; p.bias = bias; p.y = out; p.stats = stats;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin_; p.Cout = Cout_;
+    p.TY = cdiv(H, 4); p.TX = cdiv(W, 4); p.NBY = cdiv(p.TY, TBY); p.NBX = cdiv(p.TX, TBX);
+    p.off = -1; p.reflect = reflect; p.act = act; p.accumulate = accumulate;
+    p.ncb = Cout_ / NBC; p.ntb = B * p.NBY * p.NBX;
+    p.xcdmap = (p.ncb <= 8 && 8 % p.ncb == 0 && p.ntb % (8 / p.ncb) == 0) ? 1 : 0;
+    p.xbytes = (long long)B * H * W * Cin_ * 4;
+    p.ubytes = (long long)36 * Cin_ * Cout_ * 4;
+    const dim3 grid(p.ncb * p.ntb);
+    const int abl = wino_fused_mode() >> 4;
+#ifdef ACLGAN_FUSED_ABLATION
+#define ACL_ABL(A_) else if (abl == A_) hipLaunchKernelGGL((wino_fused_kernel<A_>), grid, dim3(256), 0, st, p);
+    if (abl == 0) hipLaunchKernelGGL(wino_fused_kernel<0>, grid, dim3(256), 0, st, p);
+    ACL_ABL(1) ACL_ABL(2) ACL_ABL(4) ACL_ABL(8) ACL_ABL(14) ACL_ABL(15) ACL_ABL(31) ACL_ABL(128)
+#undef ACL_ABL
+    else
+#endif
+    { (void)abl; hipLaunchKernelGGL(wino_fused_kernel<0>, grid, dim3(256), 0, st, p); }
+    ACL_CHECK_LAUNCH("wino_fused_kernel");
+    return ACLGAN_OK;
+}
+
+}  // namespace aclgan
