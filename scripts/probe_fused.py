@@ -12,8 +12,8 @@ from gpu_util import conv_desc, gpu_conv_fwd, gpu_conv_dgrad, nhwc, nchw, ohwi
 st = L.stream_ptr()
 
 
-def rel(a, b):
-    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+def rel(a, b):      # relative L2 error
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
 def ref_fwd(x, w, b, act):
@@ -21,7 +21,7 @@ def ref_fwd(x, w, b, act):
     return {"none": y, "relu": F.relu(y), "lrelu": F.leaky_relu(y, 0.2)}[act]
 
 
-CASES = [(2, 8, 8, 256, 256, "none"), (1, 12, 20, 64, 128, "relu"), (3, 4, 8, 128, 64, "none"), (2, 16, 16, 64, 64, "lrelu"),
+CASES = [(2, 16, 16, 256, 256, "none"), (2, 8, 8, 256, 256, "none"), (1, 12, 20, 64, 128, "relu"), (3, 4, 8, 128, 64, "none"), (2, 16, 16, 64, 64, "lrelu"),
          (1, 36, 40, 64, 64, "none"), (2, 64, 64, 256, 256, "none"), (1, 128, 128, 128, 128, "relu")]
 bad = 0
 for (B, H, W, Ci, Co, act) in CASES:
@@ -34,7 +34,7 @@ for (B, H, W, Ci, Co, act) in CASES:
     d = conv_desc(L, B, H, W, Ci, Co, 3, 1, 1, 0, act); dn = conv_desc(L, B, H, W, Ci, Co, 3, 1, 1, 0, "none")
     xg, wg, dyg = nhwc(x), ohwi(w), nhwc(dy)
     res = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1):
         L.lib.aclgan_set_tuning(b"wino_fused", mode)
         y = gpu_conv_fwd(L, d, xg, wg, b)
         dx = gpu_conv_dgrad(L, dn, dyg, wg)
@@ -44,8 +44,8 @@ for (B, H, W, Ci, Co, act) in CASES:
         res[mode] = (rel(nchw(y), yr), rel(nchw(dx), xr.grad), rel(nchw(acc - base), xr.grad))
     ok = all(max(r) < 2e-4 for r in res.values())
     bad += 0 if ok else 1
-    print("%-28s %s  fwd/dgrad/acc  pipeline %.1e %.1e %.1e | fused8 %.1e %.1e %.1e | fused16 %.1e %.1e %.1e" %
-          (str((B, H, W, Ci, Co, act)), "ok " if ok else "BAD", *res[0], *res[1], *res[2]), flush=True)
+    print("%-28s %s  rel L2 fwd/dgrad/acc  pipeline %.2e %.2e %.2e | fused %.2e %.2e %.2e" %
+          (str((B, H, W, Ci, Co, act)), "ok " if ok else "BAD", *res[0], *res[1]), flush=True)
 
 # Conv2dBlock forward with the statistics from the epilogue: mean / rstd / output of the following InstanceNorm
 if hasattr(L.lib, "aclgan_conv2d_block_fwd"):
@@ -71,7 +71,7 @@ for (B, H, Ci, Co) in [(8, 64, 256, 256), (4, 128, 256, 256), (8, 64, 128, 128)]
     fscr = torch.empty(L.lib.aclgan_conv2d_fwd_scratch_bytes(C.byref(d)) // 4 + 16, device="cuda")
     dscr = torch.empty(L.lib.aclgan_conv2d_dgrad_scratch_bytes(C.byref(d)) // 4 + 16, device="cuda")
     flop = 2.0 * B * H * H * Co * 9 * Ci
-    for mode in (0, 1, 2):
+    for mode in (0, 1):
         L.lib.aclgan_set_tuning(b"wino_fused", mode)
         tf = timeit(lambda: L.check(L.lib.aclgan_conv2d_fwd_ws(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(fscr), st)))
         td = timeit(lambda: L.check(L.lib.aclgan_conv2d_dgrad(C.byref(d), L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(dscr), 0, st)))
