@@ -147,9 +147,12 @@ int set_wino_x3(int v);
 int wino_fused_mode();                           // 0 off, 1 fused
 int set_wino_fused(int v);                       // returns the previous mode
 bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act = ACLGAN_ACT_NONE);
-int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st);
+int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st, int nph = 1);
 int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* Uf, const float* bias, float* out, int act, int accumulate,
                       int reflect, float2* stats, hipStream_t st);
+int wino_fused_up5_fwd(int B, int Hi, int Wi, int Cin_, int Cout_, const float* x, const float* Uf, const float* bias, float* y, int Hf, int Wf, int act,
+                       hipStream_t st);
+int wino_fused_up5_dgrad(int B, int Hi, int Wi, int Cin_, int Cout_, const float* dy, const float* Uf, float* dx, int Hf, int Wf, int accumulate, hipStream_t st);
 // gemm_bf16x3.hip: fp32-accurate GEMM slices on the bf16 matrix cores from 3-plane (h, m, l) bf16 operands
 bool gemm_x3_shape_ok(int T, int K, int N);
 int gemm_slices_x3(const void* A3, size_t a_plane, const void* B3, size_t b_plane, float* C, int T, int K, int N, int nslices, int a_mod, hipStream_t st);

@@ -46,11 +46,20 @@ constexpr int NBC = 64;                          // output channels per workgrou
 constexpr unsigned int OOBV = 0x7ffffff0u;       // buffer offset that reads zero
 constexpr int M_BYTES = 36 * 32 * 32 * 4;        // epilogue exchange buffer (one 32-channel half)
 
+// Views: a strided window onto an NHWC tensor [B][HS][WS][C]: logical pixel (iy, ix) lives at physical row y0 + s * iy, column x0 + s * ix.
+// Identity for the ResBlock layers; the sub-pixel phases of the upsample + 5x5 layers are stride-2 views of the hi-res map (conv_wino.hip).
 struct WfP {
     const float* x; const float* Uf; const float* bias; float* y; float2* stats;
-    int B, H, W, Cin, Cout, TY, TX, NBY, NBX, off, reflect, act, accumulate, ncb, ntb, xcdmap;
+    int B, Cin, Cout;                                  // Cin: input channels of ONE K phase
+    int IH, IW, ivs, ivy0, ivx0, IHS, IWS, off, reflect;      // input view (logical extent IH x IW), patch offset, padding mode
+    int nkph;                                          // K phases: the K loop runs over nkph x Cin channels (input gradient of the sub-pixel layers:
+    int kph_xoff[4];                                   //   the four phase views of dy, byte offset of view ph relative to view 0) ...
+    int uphase;                                        //   ... with U of K phase / grid phase ph starting uphase bytes after the previous one
+    int OH, OW, ovs, OHS, OWS, ovy0[4], ovx0[4];       // output view per GRID phase (blockIdx.y; forward of the sub-pixel layers: 4), logical extent
+    int TY, TX, NBY, NBX, act, accumulate, ncb, ntb, xcdmap;
     long long xbytes, ubytes;
 };
+
 
 __device__ __forceinline__ int reflf(int v, int n) {
     v = v < 0 ? -v : v;
@@ -84,6 +93,8 @@ __device__ __forceinline__ void g6f(const float (&g)[3], float (&u)[6]) {
 __global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __restrict__ w, float* __restrict__ Uf, int Co, int Ci, int flip) {
     const int R = flip ? Ci : Co, K = flip ? Co : Ci, KQ = K >> 2;
     const int64_t n = (int64_t)R * K;
+    w += (size_t)blockIdx.y * Co * 9 * Ci;            // blockIdx.y = phase (merged filters of the sub-pixel layers), else 0
+    Uf += (size_t)blockIdx.y * 36 * n;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
         // consecutive threads -> consecutive rows of one k (the 36 stores of a wave then fill 128-byte runs of the fragment layout)
         const int row = (int)(idx % R), kk = (int)(idx / R);
@@ -155,7 +166,7 @@ constexpr int UD = 8;                            // U fragments are loaded UD sl
 template <int WI, int WJ, int ABL>
 __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane, const int cb, const unsigned int (&go)[NP], const int (&lub)[NP],
                                         f32x16 (&acc)[9][2]) {
-    const int nch = p.Cin / KC, KQ = p.Cin >> 2;
+    const int nchp = p.Cin / KC, nch = nchp * p.nkph, KQp = p.Cin >> 2;      // chunks per K phase, chunks in all, 4-channel steps per phase
     const int wave = WI * 2 + WJ;
     const int l31 = lane & 31, h = lane >> 5;
     const int lanebase = (h * QS + 4 * (l31 >> 3) * RS + (l31 & 7)) * 8;      // bytes
@@ -163,13 +174,16 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Uf), 0, (int)p.ubytes, 0x00020000);
     const int uvo = lane * 8;                                                  // lane part of a U fragment address
     const int ustep = 4 * 9 * 2 * 64 * 8;                                      // bytes of one 4-channel step of a channel block
-    const int ubase = (cb * KQ * 4 + wave) * (9 * 2 * 64 * 8);
+    const int ubase = (cb * KQp * 4 + wave) * (9 * 2 * 64 * 8) + (int)blockIdx.y * p.uphase;      // (blockIdx.y: grid phase)
+    auto kphase = [&](int c) __attribute__((always_inline)) { return (c >= nchp) + (c >= 2 * nchp) + (c >= 3 * nchp); };      // scalar
     const BtK bk = {opaque2(4.f), opaque2(-5.f), opaque2(-4.f), opaque2(2.f), opaque2(-2.f)};
 
     // ---- staging of the raw patch: piece i of a chunk is issued at window slice 3i and written to LDS at slice 3i + 5 ----
     f32x4 xr[2];
     auto xissue = [&](int chunk, int i) __attribute__((always_inline)) {
-        xr[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], min(chunk, nch - 1) * KC * 4, 0));
+        const int c = min(chunk, nch - 1), ph = kphase(c);
+        const int xo = ph == 0 ? 0 : (ph == 1 ? p.kph_xoff[1] : (ph == 2 ? p.kph_xoff[2] : p.kph_xoff[3]));
+        xr[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], (c - ph * nchp) * KC * 4 + xo, 0));
     };
     auto xwrite = [&](int par, int i) __attribute__((always_inline)) {       // par: parity of the chunk = its LDS buffer (compile time)
         char* dst = smem + par * XBUF * 8 + lub[i];
@@ -183,7 +197,8 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
 
     f32x2 u[9][2];
     auto uload = [&](int kq, int fi) __attribute__((always_inline)) {
-        const int so = ubase + min(kq, KQ - 1) * ustep;                         // scalar
+        const int q = min(kq, 2 * nch - 1), ph = kphase(q >> 1);
+        const int so = ubase + ph * p.uphase + (q - ph * KQp) * ustep;           // scalar
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = fi * 2 + j;
@@ -290,6 +305,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     const int bx = tb % p.NBX, by = (tb / p.NBX) % p.NBY, b = tb / (p.NBX * p.NBY);
     const int ty0 = by * TBY, tx0 = bx * TBX;
+    const int gph = blockIdx.y;                           // grid phase (forward of the sub-pixel layers): its own U and output view
+    const int ovy0 = gph == 0 ? p.ovy0[0] : (gph == 1 ? p.ovy0[1] : (gph == 2 ? p.ovy0[2] : p.ovy0[3]));
+    const int ovx0 = gph == 0 ? p.ovx0[0] : (gph == 1 ? p.ovx0[1] : (gph == 2 ? p.ovx0[2] : p.ovx0[3]));
     // (The workgroups of an XCD share one slice of U and walk K in lockstep.  MEASURED: starting every tile block at a different input
     //  channel -- so that a U line is a first touch for one workgroup only -- is 25 % SLOWER: 128 against 103.5 us; lockstep is what
     //  keeps the slice's lines hot in the XCD's L2.)
@@ -306,9 +324,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const int pix = s / JN, j = s - pix * JN;
             const int r = pix / PC, c = pix - r * PC;
             int iy = 4 * ty0 + p.off + r, ix = 4 * tx0 + p.off + c;
-            if (p.reflect) { iy = reflf(iy, p.H); ix = reflf(ix, p.W); }
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                go[i] = (unsigned int)((((size_t)b * p.H + iy) * p.W + ix) * p.Cin * 4 + j * 16);
+            if (p.reflect) { iy = reflf(iy, p.IH); ix = reflf(ix, p.IW); }
+            if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+                go[i] = (unsigned int)((((size_t)b * p.IHS + p.ivy0 + p.ivs * iy) * p.IWS + p.ivx0 + p.ivs * ix) * p.Cin * 4 + j * 16);
             lub[i] = (2 * j * QS + r * RS + (c & 3) * 9 + (c >> 2)) * 8;
         }
     }
@@ -355,13 +373,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int tile = 16 * P + tl;
         const int ty = ty0 + (tile >> 3), tx = tx0 + (tile & 7);
         const bool live = ty < p.TY && tx < p.TX;
-        float* ybase = p.y + (((size_t)b * p.H + 4 * (live ? ty : 0)) * p.W + 4 * (live ? tx : 0)) * p.Cout + n;
+        const int rows = live ? min(4, p.OH - 4 * ty) : 0, cols = live ? min(4, p.OW - 4 * tx) : 0;      // ragged last tiles of a view
+        float* ybase = p.y + (((size_t)b * p.OHS + ovy0 + p.ovs * 4 * (live ? ty : 0)) * p.OWS + ovx0 + p.ovs * 4 * (live ? tx : 0)) * p.Cout + n;
+        const size_t yrs = (size_t)p.ovs * p.OWS * p.Cout, ycs = (size_t)p.ovs * p.Cout;
         f32x4 old[4][4];
         if (p.accumulate) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) old[a][bb] = *reinterpret_cast<const f32x4*>(ybase + ((size_t)a * p.W + bb) * p.Cout);
+                for (int bb = 0; bb < 4; ++bb) old[a][bb] = (a < rows && bb < cols) ? *reinterpret_cast<const f32x4*>(ybase + a * yrs + bb * ycs) : (f32x4)(0.f);
         }
         f32x4 tmp[4][6];
 #pragma unroll
@@ -389,7 +409,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = fmaxf(v[e], 0.f) + slope * fminf(v[e], 0.f);
                 if (p.accumulate) val += old[a][bb];
-                if (live && !(ABL & 128)) *reinterpret_cast<f32x4*>(ybase + ((size_t)a * p.W + bb) * p.Cout) = val;
+                if (a < rows && bb < cols && !(ABL & 128)) *reinterpret_cast<f32x4*>(ybase + a * yrs + bb * ycs) = val;
                 if (a == 0 && bb == 0) sh = val;
                 const f32x4 dv = val - sh;
                 s1 += dv; s2 += dv * dv;
@@ -417,37 +437,32 @@ int wino_fused_mode() {
 }
 int set_wino_fused(int v) { const int old = wino_fused_mode(); g_wino_fused = (v < 0 || (v & 15) > 1) ? 1 : v; return old; }
 
-// the fused kernel takes: K-side channels a multiple of the chunk, output channels a multiple of 64, byte offsets below 2^31
+// the fused kernel takes: K-side channels a multiple of 16, output channels a multiple of 64, byte offsets below 2^31; no tanh epilogue
 bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act) {
     const int m = wino_fused_mode() & 15;
     if (m == 0) return false;
-    return act != ACLGAN_ACT_TANH && H % 4 == 0 && W % 4 == 0 && Cin_ % (2 * KC) == 0 && Cout_ % NBC == 0 && (long long)36 * Cin_ * Cout_ * 4 < 0x7fffffe0ll && H >= 4 && W >= 4 && (long long)B * H * W * Cin_ * 4 < 0x7fffffe0ll;
+    return act != ACLGAN_ACT_TANH && Cin_ % (2 * KC) == 0 && Cout_ % NBC == 0 && (long long)4 * 36 * Cin_ * Cout_ * 4 < 0x7fffffe0ll && H >= 4 && W >= 4 &&
+           (long long)B * (2 * H + 8) * (2 * W + 8) * std::max(Cin_, Cout_) * 4 < 0x7fffffe0ll;
 }
 size_t wino_fused_u_bytes(int Cin_, int Cout_) { return (size_t)36 * Cin_ * Cout_ * sizeof(float); }
 
-// Uf <- fragment-ordered G g G^T of w (flip: the flipped, transposed filter of the input gradient)
-int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st) {
+// Uf <- fragment-ordered G g G^T of w (flip: the flipped, transposed filter of the input gradient); nph filters back to back
+int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st, int nph) {
     const int64_t n = (int64_t)Co * Ci;
-    hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, w, Uf, Co, Ci, flip);
+    hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096), nph), dim3(256), 0, st, w, Uf, Co, Ci, flip);
     ACL_CHECK_LAUNCH("wino_filter_frag_kernel");
     return ACLGAN_OK;
 }
 
-// out[B][H][W][Cout_] (+)= act(conv3x3(in[B][H][W][Cin_]) + bias) with U already in fragment order; reflect: reflection padding 1,
-// else zero padding.  stats (optional): [B][H/4 * W/4][Cout_] (mean, M2) of the 4x4 output tiles.
-int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* Uf, const float* bias, float* out, int act, int accumulate,
-                      int reflect, float2* stats, hipStream_t st) {
-    if (!wino_fused_ok(B, H, W, Cin_, Cout_, act)) return ACLGAN_EUNSUPPORTED;
-    WfP p;
-    p.x = in; p.Uf = Uf; p.bias = bias; p.y = out; p.stats = stats;
-    p.B = B; p.H = H; p.W = W; p.Cin = Cin_; p.Cout = Cout_;
-    p.TY = cdiv(H, 4); p.TX = cdiv(W, 4); p.NBY = cdiv(p.TY, TBY); p.NBX = cdiv(p.TX, TBX);
-    p.off = -1; p.reflect = reflect; p.act = act; p.accumulate = accumulate;
-    p.ncb = Cout_ / NBC; p.ntb = B * p.NBY * p.NBX;
+namespace {
+int wino_fused_go(WfP& p, int ngph, hipStream_t st) {
+    p.TY = cdiv(p.OH, 4); p.TX = cdiv(p.OW, 4); p.NBY = cdiv(p.TY, TBY); p.NBX = cdiv(p.TX, TBX);
+    p.ncb = p.Cout / NBC; p.ntb = p.B * p.NBY * p.NBX;
     p.xcdmap = (p.ncb <= 8 && 8 % p.ncb == 0 && p.ntb % (8 / p.ncb) == 0) ? 1 : 0;
-    p.xbytes = (long long)B * H * W * Cin_ * 4;
-    p.ubytes = (long long)36 * Cin_ * Cout_ * 4;
-    const dim3 grid(p.ncb * p.ntb);
+    p.xbytes = (long long)p.B * p.IHS * p.IWS * p.Cin * 4;
+    p.uphase = 36 * p.Cin * p.Cout * 4;
+    p.ubytes = (long long)p.uphase * p.nkph * ngph;
+    const dim3 grid(p.ncb * p.ntb, ngph);
     const int abl = wino_fused_mode() >> 4;
 #ifdef ACLGAN_FUSED_ABLATION
 #define ACL_ABL(A_) else if (abl == A_) hipLaunchKernelGGL((wino_fused_kernel<A_>), grid, dim3(256), 0, st, p);
@@ -459,6 +474,54 @@ int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in,
     { (void)abl; hipLaunchKernelGGL(wino_fused_kernel<0>, grid, dim3(256), 0, st, p); }
     ACL_CHECK_LAUNCH("wino_fused_kernel");
     return ACLGAN_OK;
+}
+}  // namespace
+
+// out[B][H][W][Cout_] (+)= act(conv3x3(in[B][H][W][Cin_]) + bias) with U already in fragment order; reflect: reflection padding 1,
+// else zero padding.  stats (optional): [B][H/4 * W/4][Cout_] (mean, M2) of the 4x4 output tiles.  H, W multiples of 4.
+int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* Uf, const float* bias, float* out, int act, int accumulate,
+                      int reflect, float2* stats, hipStream_t st) {
+    if (!wino_fused_ok(B, H, W, Cin_, Cout_, act) || H % 4 != 0 || W % 4 != 0) return ACLGAN_EUNSUPPORTED;
+    WfP p;
+    p.x = in; p.Uf = Uf; p.bias = bias; p.y = out; p.stats = stats;
+    p.B = B; p.Cin = Cin_; p.Cout = Cout_;
+    p.IH = H; p.IW = W; p.ivs = 1; p.ivy0 = 0; p.ivx0 = 0; p.IHS = H; p.IWS = W; p.off = -1; p.reflect = reflect;
+    p.nkph = 1;
+    for (int i = 0; i < 4; ++i) { p.kph_xoff[i] = 0; p.ovy0[i] = 0; p.ovx0[i] = 0; }
+    p.OH = H; p.OW = W; p.ovs = 1; p.OHS = H; p.OWS = W;
+    p.act = act; p.accumulate = accumulate;
+    return wino_fused_go(p, 1, st);
+}
+
+// The four VALID 3x3 phase convolutions of an "Upsample(2) + ReflectionPad2d(2) + Conv2d(5x5)" layer (conv_wino.hip, conv_fast.hip up5_*):
+// phase (py, px) of the hi-res output y[B][Hf][Wf][Cout_] at (2 (oy + 1) + py, 2 (ox + 1) + px), oy < Hi - 2, ox < Wi - 2, from the low-res input
+// x[B][Hi][Wi][Cin_].  Uf: the four merged phase filters in fragment order, back to back.  One launch, blockIdx.y = phase.
+int wino_fused_up5_fwd(int B, int Hi, int Wi, int Cin_, int Cout_, const float* x, const float* Uf, const float* bias, float* y, int Hf, int Wf, int act,
+                       hipStream_t st) {
+    if (!wino_fused_ok(B, Hi, Wi, Cin_, Cout_, act) || Hi < 6 || Wi < 6) return ACLGAN_EUNSUPPORTED;
+    WfP p;
+    p.x = x; p.Uf = Uf; p.bias = bias; p.y = y; p.stats = nullptr;
+    p.B = B; p.Cin = Cin_; p.Cout = Cout_;
+    p.IH = Hi; p.IW = Wi; p.ivs = 1; p.ivy0 = 0; p.ivx0 = 0; p.IHS = Hi; p.IWS = Wi; p.off = 0; p.reflect = 0;
+    p.nkph = 1;
+    for (int i = 0; i < 4; ++i) { p.kph_xoff[i] = 0; p.ovy0[i] = 2 + (i >> 1); p.ovx0[i] = 2 + (i & 1); }
+    p.OH = Hi - 2; p.OW = Wi - 2; p.ovs = 2; p.OHS = Hf; p.OWS = Wf;
+    p.act = act; p.accumulate = 0;
+    return wino_fused_go(p, 4, st);
+}
+// ... and their input gradient: dx[B][Hi][Wi][Cin_] (+)= sum over the phases of the full correlation of the phase view of dy[B][Hf][Wf][Cout_]
+// with the flipped merged filter: ONE K loop over (phase, cout), the sum over the phases happens in the accumulators.
+int wino_fused_up5_dgrad(int B, int Hi, int Wi, int Cin_, int Cout_, const float* dy, const float* Uf, float* dx, int Hf, int Wf, int accumulate, hipStream_t st) {
+    if (!wino_fused_ok(B, Hi, Wi, Cout_, Cin_, ACLGAN_ACT_NONE) || Hi < 6 || Wi < 6) return ACLGAN_EUNSUPPORTED;
+    WfP p;
+    p.x = dy; p.Uf = Uf; p.bias = nullptr; p.y = dx; p.stats = nullptr;
+    p.B = B; p.Cin = Cout_; p.Cout = Cin_;
+    p.IH = Hi - 2; p.IW = Wi - 2; p.ivs = 2; p.ivy0 = 2; p.ivx0 = 2; p.IHS = Hf; p.IWS = Wf; p.off = -2; p.reflect = 0;
+    p.nkph = 4;
+    for (int i = 0; i < 4; ++i) { p.kph_xoff[i] = ((i >> 1) * Wf + (i & 1)) * Cout_ * 4; p.ovy0[i] = 0; p.ovx0[i] = 0; }
+    p.OH = Hi; p.OW = Wi; p.ovs = 1; p.OHS = Hi; p.OWS = Wi;
+    p.act = ACLGAN_ACT_NONE; p.accumulate = accumulate;
+    return wino_fused_go(p, 1, st);
 }
 
 }  // namespace aclgan
