@@ -315,7 +315,7 @@ def key_list():
     json.dump(order, open(os.path.join(HERE, "param_order.json"), "w"), indent=0)
 
 
-if __name__ == "__main__" and "--checkpoint-only" not in sys.argv:
+if __name__ == "__main__" and "--checkpoint-only" not in sys.argv and "--loop-only" not in sys.argv:
     torch.manual_seed(0)
     op_vectors()
     key_list()
@@ -352,5 +352,106 @@ def checkpoint_fixture():
     print("checkpoint fixture:", meta)
 
 
+def loop_fixture():
+    """Iterations of the reference's own training LOOP, not only of its two update methods: the loop body is taken from the
+    reference's source text AT GENERATION TIME (train.py lines 65-104: D / G cadence on the per-epoch index `it`,
+    update_learning_rate() every iteration, snapshot cadence, exit at max_iter) and executed around the imported reference trainer,
+    with the data loaders replaced by fixed batches and the TensorBoard / image writers by recorders.  Nothing of that text is
+    stored: the fixture holds the batches, the style noise in draw order, and per iteration which updates ran, the 16 loss
+    attributes, both learning rates and the snapshot calls.  Hyper-parameters chosen so that every branch of the cadence is crossed in
+    6 iterations: D_update 1, G_update 2, epochs of 3 batches (`it` restarts at iteration 3: the generator update there tells the
+    per-epoch index from the global one), StepLR step_size 2 (two decays),
+    snapshot every 4."""
+    import contextlib
+    import textwrap
+    cfg = reduced_config()
+    cfg.update(focus_epsilon=0.5, D_update=1, G_update=2, step_size=2, gamma=0.5, max_iter=6, log_iter=1,
+               image_save_iter=10 ** 9, image_display_iter=10 ** 9, snapshot_save_iter=4)
+    dd = torch.float64
+    tr = ref_trainer.aclgan_Trainer(cfg)
+    fill_reference(tr, cfg)
+    tr = tr.double()
+    g = torch.Generator().manual_seed(7)
+    B, H, W, NB = 2, 64, 64, 3
+    batches_a = [(torch.rand(B, 3, H, W, generator=g) * 2 - 1) for _ in range(NB)]
+    batches_b = [(torch.rand(B, 3, H, W, generator=g) * 2 - 1) for _ in range(NB)]
+    zs = [torch.randn(B, 8, 1, 1, generator=g) for _ in range(3 * 12)]
+    records, calls, saves = [], [], []
+    orig_dis, orig_gen = tr.dis_update, tr.gen_update
+    tr.dis_update = lambda *a, **k: (calls.append("dis"), orig_dis(*a, **k))[1]
+    tr.gen_update = lambda *a, **k: (calls.append("gen"), orig_gen(*a, **k))[1]
+    tr.save = lambda d, it: saves.append(int(it))
+
+    def write_loss(iterations, trainer, train_writer):      # utils.py:174-178 logs every attribute that starts with loss_
+        rec = {"iterations": int(iterations), "calls": list(calls),
+               "lr_gen": float(trainer.gen_opt.param_groups[0]["lr"]), "lr_dis": float(trainer.dis_opt.param_groups[0]["lr"]),
+               "losses": {n: float(getattr(trainer, n).detach()) for n in LOSS_NAMES_DIS + LOSS_NAMES_GEN if hasattr(trainer, n)}}
+        del calls[:]
+        records.append(rec)
+
+    @contextlib.contextmanager
+    def Timer(msg):
+        yield
+
+    src = open(os.path.join(REF, "train.py")).read().splitlines()
+    assert src[64].startswith("while True:") and "sys.exit('Finish training')" in src[103], "reference train.py moved"
+    body = textwrap.dedent("\n".join(src[64:104]))
+    env = {"trainer": tr, "config": cfg, "iterations": 0, "max_iter": cfg["max_iter"], "torch": torch, "sys": sys, "Timer": Timer,
+           "write_loss": write_loss, "train_writer": None, "checkpoint_directory": "unused",
+           "train_loader_a": [t.to(dd) for t in batches_a], "train_loader_b": [t.to(dd) for t in batches_b]}
+    sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        with RandnQueue([z.to(dd) for z in zs]) as q:
+            try:
+                exec(compile(body, "<reference train.py:65-104>", "exec"), env)
+            except SystemExit as e:
+                assert "Finish training" in str(e)
+            used = len(zs) - len(q.items)
+    finally:
+        torch.cuda.synchronize = sync
+    out = {}
+    for i in range(NB):
+        out["x_a%d" % i] = batches_a[i].numpy(); out["x_b%d" % i] = batches_b[i].numpy()
+    for i in range(used):
+        out["z%d" % i] = zs[i].numpy()
+    final = {}
+    for name in O.OracleTrainer.NETS:
+        for k, p in getattr(tr, name).named_parameters():
+            final["%s/%s" % (name, k)] = tstats(p)
+    meta = {"config": cfg, "B": B, "H": H, "W": W, "batches_per_epoch": NB, "n_z": used, "records": records, "saves": saves,
+            "final_iterations": int(env["iterations"]), "param_stats_final": final, "dtype": "float64 reference"}
+    np.savez_compressed(os.path.join(HERE, "loop_reduced_64.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "loop_reduced_64.json"), "w"), indent=1, sort_keys=True)
+    print("loop fixture: %d iterations, updates per iteration %s, lr_gen %s, snapshots at %s, %d noise tensors"
+          % (len(records), [r["calls"] for r in records], [r["lr_gen"] for r in records], saves, used))
+
+    # pin the oracle + the build's loop function: the fp64 oracle driven by acl-gan_amd/train_loop.py reproduces the reference's loop
+    sys.path.insert(0, os.path.join(ROOT, "acl-gan_amd"))
+    import train_loop
+    nets = O.test_nets(cfg, seed=cfg.get("_fill_seed", 0))
+    orc = O.OracleTrainer(cfg, nets={k: {n: t.to(dd) for n, t in v.items()} for k, v in nets.items()})
+    zq = [z.to(dd) for z in zs]
+
+    class Adapter:
+        def dis_update(self, a, b, hp, z=None): orc.dis_update(a, b, z)
+        def gen_update(self, a, b, hp, z=None): orc.gen_update(a, b, z)
+        def update_learning_rate(self): orc.update_learning_rate()
+    seen = []
+    train_loop.run_epochs(Adapter(), lambda: zip([t.to(dd) for t in batches_a], [t.to(dd) for t in batches_b]), cfg,
+                          z_source=lambda kind: [zq.pop(0), zq.pop(0), zq.pop(0)],
+                          on_iteration=lambda info: seen.append((info["ran_dis"], info["ran_gen"], dict(orc.losses), orc._lr())))
+    worst = 0.0
+    for rec, (rd, rg, lo, lr) in zip(records, seen):
+        assert rec["calls"] == (["dis"] if rd else []) + (["gen"] if rg else []), (rec["calls"], rd, rg)
+        assert abs(lr - rec["lr_gen"]) < 1e-18, (lr, rec["lr_gen"])
+        for n, v in rec["losses"].items():
+            worst = max(worst, abs(lo[n] - v) / max(1e-6, abs(v)))
+    print("loop fixture: fp64 oracle through train_loop.run_epochs vs the reference loop: losses %.2e" % worst)
+    assert len(seen) == len(records) and worst < 1e-8, worst
+
+
 if __name__ == "__main__" and "--checkpoint-only" in sys.argv:
     checkpoint_fixture()
+if __name__ == "__main__" and "--loop-only" in sys.argv:
+    loop_fixture()

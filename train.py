@@ -110,30 +110,27 @@ def main():
         epoch = lambda: zip(train_loader_a, train_loader_b)                      # train.py:66
         if is_main:
             print("data: %d / %d training images, device input pipeline, %d rank(s) x batch %d" % (len(train_loader_a.source), len(train_loader_b.source), world, B))
-    while True:
-        for it, (images_a, images_b) in enumerate(epoch()):
-            t0 = time.time()
-            if it % config["D_update"] == 0:          # train.py:71-72 (per-epoch index, like the reference)
-                trainer.dis_update(images_a, images_b, config)
-            if it % config["G_update"] == 0:          # train.py:73-74
-                trainer.gen_update(images_a, images_b, config)
-            if is_main and (iterations + 1) % config["log_iter"] == 0:
-                vals = trainer._losses.cpu()          # one D2H copy, implies the sync of train.py:75
-                print("Iteration: %08d/%08d  %.3fs  " % (iterations + 1, max_iter, time.time() - t0) +
-                      " ".join("%s=%.4g" % (n[5:], float(vals[i])) for i, n in enumerate(L.LOSS_NAMES)
-                               if n in ("loss_gen_total", "loss_dis_total", "loss_idt_A", "loss_gen_adv_A")))
-            if is_main and (iterations + 1) % config["snapshot_save_iter"] == 0:      # replicas are identical: rank 0's copy is THE checkpoint
-                trainer.save(checkpoint_directory, iterations)
-            trainer.update_learning_rate()            # train.py:101
-            iterations += 1
-            if iterations >= max_iter:
-                if is_main:
-                    trainer.save(checkpoint_directory, iterations - 1)
-                    print("Finish training")
-                if world > 1:
-                    dist.barrier()
-                    dist.destroy_process_group()
-                return
+    from aclgan_amd.train_loop import run_epochs, snapshot_due, log_due
+    clock = {"t0": time.time()}
+
+    def on_iteration(info):      # train.py:78-99: log / snapshot, between the updates and the learning-rate step
+        iterations = info["iterations"]
+        if is_main and log_due(iterations, config):
+            vals = trainer._losses.cpu()          # one D2H copy, implies the sync of train.py:75
+            print("Iteration: %08d/%08d  %.3fs  " % (iterations + 1, max_iter, time.time() - clock["t0"]) +
+                  " ".join("%s=%.4g" % (n[5:], float(vals[i])) for i, n in enumerate(L.LOSS_NAMES)
+                           if n in ("loss_gen_total", "loss_dis_total", "loss_idt_A", "loss_gen_adv_A")))
+        if is_main and snapshot_due(iterations, config):      # replicas are identical: rank 0's copy is THE checkpoint
+            trainer.save(checkpoint_directory, iterations)
+        clock["t0"] = time.time()
+
+    iterations = run_epochs(trainer, epoch, config, iterations=iterations, max_iter=max_iter, on_iteration=on_iteration)
+    if is_main:
+        trainer.save(checkpoint_directory, iterations - 1)
+        print("Finish training")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
