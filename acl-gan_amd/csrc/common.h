@@ -212,6 +212,10 @@ int focus_blend_fwd(int B, int HW, const float* dec4, const float* bg, float* ou
 // caller), d_bg (+= if accumulate else =; may be null)
 int focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const float* d_out, const float* d_pair,
                     float* d_dec4, float* d_bg, int bg_accumulate, hipStream_t st);
+// non-focus configuration (gen.output_dim 3, trainer.py:117-121,129-133): out = dec3, pair (optional) = (pair_first, dec3); backward adds d_out and
+// d_pair[.., 3:6] onto d_dec3
+int plain_pair_fwd(int B, int HW, const float* dec3, float* out, const float* pair_first, float* pair, hipStream_t st);
+int plain_pair_bwd(int B, int HW, const float* d_out, const float* d_pair, float* d_dec3, hipStream_t st);
 // focus_translation on the reference's own NCHW tensors (sample() / test.py: trainer.py:85-88, test.py:73-76):
 // out[b][c][p] = fg[b][c][p]*m + bg[b][c][p]*(1-m), m = (focus[b][0][p]+1)/2, c < 3; *_bstride = floats between samples
 int focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg, int64_t bg_bstride, const float* focus, int64_t focus_bstride,

@@ -770,8 +770,10 @@ static int blend(aclgan_ctx& c, Act* dec4, Act* bg, Act* pair_first, Act** out_p
             NEED(pair->d); if (want) NEED(pair->g);
         }
     }
-    RUN(focus_blend_fwd(dec4->B, dec4->H * dec4->W, dec4->d, bg->d, out->d, pair_first ? pair_first->d : nullptr, pair ? pair->d : nullptr, c.st));
-    c.count(4.0 * (double)dec4->B * dec4->H * dec4->W * (4 + 3 + 3 + (pair_first ? 9 : 0)) * (want ? 2.0 : 1.0));
+    const bool plain = dec4->C == 3;      // non-focus configuration (trainer.py:117-121,129-130): the decoder output is the image itself
+    if (plain) RUN(plain_pair_fwd(dec4->B, dec4->H * dec4->W, dec4->d, out->d, pair_first ? pair_first->d : nullptr, pair ? pair->d : nullptr, c.st));
+    else RUN(focus_blend_fwd(dec4->B, dec4->H * dec4->W, dec4->d, bg->d, out->d, pair_first ? pair_first->d : nullptr, pair ? pair->d : nullptr, c.st));
+    c.count(4.0 * (double)dec4->B * dec4->H * dec4->W * ((plain ? 3 : 4 + 3) + 3 + (pair_first ? 9 : 0)) * (want ? 2.0 : 1.0));
     *out_p = out;
     if (pair_p) *pair_p = pair;
     if (!want) return ACLGAN_OK;
@@ -781,6 +783,7 @@ static int blend(aclgan_ctx& c, Act* dec4, Act* bg, Act* pair_first, Act** out_p
         const float* dout = out->written() ? out->g : nullptr;
         const float* dpair = (pair && pair->written()) ? pair->g : nullptr;
         if (!dout && !dpair) return ACLGAN_OK;
+        if (plain) { RUN(plain_pair_bwd(dec4->B, dec4->H * dec4->W, dout, dpair, dec4->g, c.st)); return ACLGAN_OK; }
         float* dbg = bg->need_grad ? bg->g : nullptr;
         RUN(focus_blend_bwd(dec4->B, dec4->H * dec4->W, dec4->d, bg->d, dout, dpair, dec4->g, dbg, bg->gw ? 1 : 0, c.st));
         if (dbg) mark_written(bg);
@@ -899,10 +902,12 @@ static int check_shape(const aclgan_ctx& c, int B, int H, int W) {
 static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, const float* z, int B, int H, int W,
                            const aclgan_hparams& hp, float* L) {
     CHK(check_shape(c, B, H, W));
-    if (!(hp.focus_loss > 0.f)) {
-        set_error("focus_loss <= 0: the reference's non-focus branch feeds a 4-channel image to 3-channel discriminators and cannot run");
-        return ACLGAN_EUNSUPPORTED;
-    }
+    // focus branch (trainer.py:107-116,126-128,145-161): gen.output_dim 4 = image + focus mask.  Non-focus branch (focus_loss 0,
+    // trainer.py:117-121,129-130: the paper's ablation): the decoder output is the image, which only type-checks against the 3-channel
+    // discriminators with gen.output_dim 3.
+    const bool focus = hp.focus_loss > 0.f;
+    ACL_REQUIRE(c.arch.gen_output_dim == (focus ? 4 : 3), "focus_loss %s 0 needs gen.output_dim %d (trainer.py:107-121), the context was built with %d",
+                focus ? ">" : "<=", focus ? 4 : 3, c.arch.gen_output_dim);
     const int sd = c.arch.gen_style_dim;
     const int AB = ACLGAN_NET_GEN_AB, BA = ACLGAN_NET_GEN_BA;
     const int nfs = 2 * focus_sums_blocks((int64_t)B * H * W);   // per-workgroup partials of the focus sums, one set per mask
@@ -957,13 +962,13 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     // the gradient all-reduce averages over ranks
     float* ftot = nullptr;
     if (c.sync_fn) { ftot = c.allocf(8); NEED(ftot); }
-    for (int i = 0; i < 3; ++i) RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, hp.focus_upper, sums + (size_t)i * nfs, c.st));
-    c.count(4.0 * (double)npix * (3 * 2 + 2 * (4 + 3 + 4)));     // focus masks read + gradient written; L1: decoder output, image, gradient
-    if (ftot) {
+    for (int i = 0; i < 3 && focus; ++i) RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, hp.focus_upper, sums + (size_t)i * nfs, c.st));
+    c.count(4.0 * (double)npix * ((focus ? 3 * 2 : 0) + 2 * (4 + 3 + 4)));     // focus masks read + gradient written; L1: decoder output, image, gradient
+    if (ftot && focus) {
         RUN(focus_totals(sums, npix, 3, ftot, c.st));
         if (!c.dry) c.sync_fn(c.sync_user, ftot, 6);
     }
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3 && focus; ++i)
         RUN(focus_loss_finish(fl[i].a->d, npix, sums + (size_t)i * nfs, hp.focus_delta, hp.focus_upper, hp.focus_lower, hp.focus_epsilon, fscale,
                               L + fl[i].size_slot, L + fl[i].digit_slot, fl[i].a->g, c.st, c.lscale, ftot ? ftot + 2 * i : nullptr,
                               npix * (int64_t)c.sync_world));
@@ -972,8 +977,8 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         const size_t mark = c.top;
         float* l1p = c.allocf(2 * L1_PART_FLOATS);     // workgroup partials of the two L1 sums: added in a fixed order
         NEED(l1p);
-        RUN(l1_loss(rA4->d, 4, xa->d, npix, L + ACLGAN_L_IDT_A, rA4->g, hp.recon_x_w, 1, c.st, c.lscale, l1p));
-        RUN(l1_loss(rB4->d, 4, xb->d, npix, L + ACLGAN_L_IDT_B, rB4->g, hp.recon_x_w, 1, c.st, c.lscale, l1p + L1_PART_FLOATS));
+        RUN(l1_loss(rA4->d, rA4->C, xa->d, npix, L + ACLGAN_L_IDT_A, rA4->g, hp.recon_x_w, 1, c.st, c.lscale, l1p));
+        RUN(l1_loss(rB4->d, rB4->C, xb->d, npix, L + ACLGAN_L_IDT_B, rB4->g, hp.recon_x_w, 1, c.st, c.lscale, l1p + L1_PART_FLOATS));
         c.top = mark;
     }
     if (!c.dry) {
@@ -987,7 +992,9 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
 static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, const float* z, int B, int H, int W,
                            const aclgan_hparams& hp, float* L) {
     CHK(check_shape(c, B, H, W));
-    if (!(hp.focus_loss > 0.f)) { set_error("focus_loss <= 0 unsupported (see gen_update)"); return ACLGAN_EUNSUPPORTED; }
+    const bool focus = hp.focus_loss > 0.f;      // trainer.py:266-276: same two branches as gen_update
+    ACL_REQUIRE(c.arch.gen_output_dim == (focus ? 4 : 3), "focus_loss %s 0 needs gen.output_dim %d (trainer.py:266-276), the context was built with %d",
+                focus ? ">" : "<=", focus ? 4 : 3, c.arch.gen_output_dim);
     const int sd = c.arch.gen_style_dim;
     const int AB = ACLGAN_NET_GEN_AB, BA = ACLGAN_NET_GEN_BA;
     if (!c.dry) {
@@ -1043,7 +1050,7 @@ extern "C" {
 int aclgan_ctx_create(const aclgan_arch* arch, aclgan_ctx** out) {
     ACL_REQUIRE(arch && out, "null argument");
     ACL_REQUIRE(arch->input_dim_a == 3 && arch->input_dim_b == 6, "input_dim_a must be 3 and input_dim_b 6 (trainer.py:19-23,132-133)");
-    ACL_REQUIRE(arch->gen_output_dim == 4, "gen.output_dim must be 4 (image + focus mask, trainer.py:108)");
+    ACL_REQUIRE(arch->gen_output_dim == 4 || arch->gen_output_dim == 3, "gen.output_dim must be 4 (image + focus mask, trainer.py:108) or 3 (non-focus configuration, trainer.py:117-121)");
     ACL_REQUIRE(arch->gen_dim >= 4 && (arch->gen_dim & (arch->gen_dim - 1)) == 0, "gen.dim must be a power of two >= 4");
     ACL_REQUIRE(arch->dis_dim >= 4 && arch->dis_dim % 4 == 0, "dis.dim must be a multiple of 4");
     ACL_REQUIRE(arch->gen_n_downsample >= 1 && arch->gen_n_res >= 1 && arch->dis_n_layer >= 1 && arch->dis_num_scales >= 1, "bad layer counts");
@@ -1116,7 +1123,7 @@ int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out) {
     ACL_REQUIRE(c.groups[0].param && c.groups[1].param, "bind parameters first");
     aclgan_hparams hp;
     memset(&hp, 0, sizeof hp);
-    hp.focus_loss = 1.f; hp.alpha = 1.f;
+    hp.focus_loss = c.arch.gen_output_dim == 4 ? 1.f : 0.f; hp.alpha = 1.f;      // (the branch the architecture can run: gen.output_dim 4 = focus, 3 = non-focus)
     size_t best = 0;
     for (int which = 0; which < 2; ++which) {
         c.reset_step();
@@ -1138,7 +1145,7 @@ int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int 
     ACL_REQUIRE(c.groups[0].param && c.groups[1].param, "bind parameters first");
     aclgan_hparams hp;
     memset(&hp, 0, sizeof hp);
-    hp.focus_loss = 1.f; hp.alpha = 1.f;
+    hp.focus_loss = c.arch.gen_output_dim == 4 ? 1.f : 0.f; hp.alpha = 1.f;      // (the branch the architecture can run: gen.output_dim 4 = focus, 3 = non-focus)
     c.reset_step();
     c.dry = true; c.peak = 0; c.trained = which; c.alg_bytes = 0.0;
     const aclgan_bucket_fn keep = c.bucket_fn;
@@ -1247,7 +1254,7 @@ int aclgan_bucket_schedule(aclgan_ctx* ctx, int group, int B, int H, int W, int 
     ACL_REQUIRE(c.bucket_elems > 0, "aclgan_set_grad_buckets first");
     aclgan_hparams hp;
     memset(&hp, 0, sizeof hp);
-    hp.focus_loss = 1.f; hp.alpha = 1.f;
+    hp.focus_loss = c.arch.gen_output_dim == 4 ? 1.f : 0.f; hp.alpha = 1.f;      // (the branch the architecture can run: gen.output_dim 4 = focus, 3 = non-focus)
     c.reset_step();
     c.dry = true; c.peak = 0; c.trained = group; c.fire_dry = fire != 0;
     const int rc = group == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)

@@ -399,6 +399,39 @@ int focus_blend_bwd(int B, int HW, const float* dec4, const float* bg, const flo
     return ACLGAN_OK;
 }
 
+// ---- the non-focus configuration (gen.output_dim 3, focus_loss 0; trainer.py:117-121,129-133): the decoder output IS the translated image.
+// out = dec3; pair (optional) = (pair_first, dec3).  Backward: d_dec3 += d_out + d_pair[.., 3:6].
+__global__ void plain_pair_fwd_kernel(const float* __restrict__ dec3, float* __restrict__ out, const float* __restrict__ first, float* __restrict__ pair,
+                                      int64_t npix) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        const float o0 = dec3[3 * i], o1 = dec3[3 * i + 1], o2 = dec3[3 * i + 2];
+        out[3 * i] = o0; out[3 * i + 1] = o1; out[3 * i + 2] = o2;
+        if (pair) {
+            pair[6 * i] = first[3 * i]; pair[6 * i + 1] = first[3 * i + 1]; pair[6 * i + 2] = first[3 * i + 2];
+            pair[6 * i + 3] = o0; pair[6 * i + 4] = o1; pair[6 * i + 5] = o2;
+        }
+    }
+}
+int plain_pair_fwd(int B, int HW, const float* dec3, float* out, const float* pair_first, float* pair, hipStream_t st) {
+    const int64_t n = (int64_t)B * HW;
+    hipLaunchKernelGGL(plain_pair_fwd_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, dec3, out, pair_first, pair, n);
+    ACL_CHECK_LAUNCH("plain_pair_fwd_kernel");
+    return ACLGAN_OK;
+}
+__global__ void plain_pair_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ d_pair, float* __restrict__ d_dec3, int64_t npix) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        float g0 = d_out ? d_out[3 * i] : 0.f, g1 = d_out ? d_out[3 * i + 1] : 0.f, g2 = d_out ? d_out[3 * i + 2] : 0.f;
+        if (d_pair) { g0 += d_pair[6 * i + 3]; g1 += d_pair[6 * i + 4]; g2 += d_pair[6 * i + 5]; }
+        d_dec3[3 * i] += g0; d_dec3[3 * i + 1] += g1; d_dec3[3 * i + 2] += g2;      // accumulate: the buffer is zero-initialised by the caller
+    }
+}
+int plain_pair_bwd(int B, int HW, const float* d_out, const float* d_pair, float* d_dec3, hipStream_t st) {
+    const int64_t n = (int64_t)B * HW;
+    hipLaunchKernelGGL(plain_pair_bwd_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, st, d_out, d_pair, d_dec3, n);
+    ACL_CHECK_LAUNCH("plain_pair_bwd_kernel");
+    return ACLGAN_OK;
+}
+
 __global__ void focus_translation_nchw_kernel(const float* __restrict__ fg, int64_t fgs, const float* __restrict__ bg, int64_t bgs,
                                               const float* __restrict__ fo, int64_t fos, float* __restrict__ out, int HW, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {

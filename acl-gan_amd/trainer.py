@@ -602,11 +602,11 @@ class aclgan_Trainer:
         return out
 
     def sample(self, x_a, x_b):
-        """trainer.py:179-245, focus branch: per-image eval forward; returns the same 9-tuple."""
-        if not (self.focus_lam > 0):
-            raise L.AclganError("sample(): only the focus branch is supported")
+        """trainer.py:179-245: per-image eval forward; returns the reference's 9-tuple (focus branch) or 7-tuple (focus_loss == 0)."""
         x_a = x_a.to(self.device, torch.float32)
         x_b = x_b.to(self.device, torch.float32)
+        if not (self.focus_lam > 0):
+            return self._sample_plain(x_a, x_b)
         X_A, X_B, A_fake, B_fake, A2_fake, m_A, m_B, m_A2, m_rec, A_rec = [], [], [], [], [], [], [], [], [], []
         for i in range(x_a.size(0)):
             xa = x_a[i].unsqueeze(0)
@@ -625,6 +625,26 @@ class aclgan_Trainer:
             A2_fake.append(self.focus_translation(img, xb_img, mask)); m_A2.append(mask)
         cat = torch.cat
         return (cat(X_A), cat(A_fake), cat(m_A), cat(B_fake), cat(m_B), cat(A2_fake), cat(m_A2), cat(A_rec), cat(m_rec))
+
+    def _sample_plain(self, x_a, x_b):
+        """trainer.py:216-230,238-245 (non-focus configuration).  Faithful to the reference including its quirk at :228-229: the B
+        reconstruction encodes the WHOLE batch x_b inside the per-image loop, so x_B_recon comes back as B copies of the batch."""
+        X_A, X_B, A_fake, B_fake, A2_fake, A_rec, B_rec = [], [], [], [], [], [], []
+        for i in range(x_a.size(0)):
+            xa = x_a[i].unsqueeze(0)
+            X_A.append(xa); X_B.append(x_b[i].unsqueeze(0))
+            c_1, s_1 = self.gen_BA.encode(xa)
+            A_fake.append(self.gen_BA.decode(c_1, self.z_1[i].unsqueeze(0)))
+            A_rec.append(self.gen_BA.decode(c_1, s_1))
+            c_2, _ = self.gen_AB.encode(xa)
+            x_B1 = self.gen_AB.decode(c_2, self.z_2[i].unsqueeze(0))
+            B_fake.append(x_B1)
+            c_3, _ = self.gen_BA.encode(x_B1)
+            A2_fake.append(self.gen_BA.decode(c_3, self.z_3[i].unsqueeze(0)))
+            c_4, s_4 = self.gen_AB.encode(x_b)
+            B_rec.append(self.gen_AB.decode(c_4, s_4))
+        cat = torch.cat
+        return (cat(X_A), cat(A_fake), cat(B_fake), cat(A2_fake), cat(A_rec), cat(X_B), cat(B_rec))
 
     # ---- checkpoints (trainer.py:301-331, utils.py:211-220) ----
     def _opt_state_dict(self, grp):

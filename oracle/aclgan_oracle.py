@@ -537,24 +537,35 @@ def focus_losses(focus, hp):
 
 def generator_forward(G_AB: Params, G_BA: Params, x_a, x_b, z, hp, with_recon: bool):
     """The shared generator forward of gen_update / dis_update (trainer.py:103-133 /
-    258-277), focus branch (focus_loss > 0).  ``z`` = (z_1, z_2, z_3), each (B, style_dim, 1, 1)."""
+    258-277): the focus branch (focus_loss > 0: decoder output = image + focus mask, trainer.py:107-116,126-128) or the non-focus
+    branch (focus_loss == 0, gen.output_dim 3: the decoder output is the image, trainer.py:117-121,129-130).
+    ``z`` = (z_1, z_2, z_3), each (B, style_dim, 1, 1)."""
     g = hp["gen"]
     z1, z2, z3 = z
     alpha = hp["alpha"]
+    focus = hp["focus_loss"] > 0
     c1 = content_encode(G_AB, x_a, g)
     c2, s2 = gen_encode(G_BA, x_a, g)
     out = {}
-    xB, fB = decode(G_AB, c1, z1, g).split(3, 1)
-    xA, fA = decode(G_BA, c2, alpha * z2, g).split(3, 1)
-    xB = focus_translation(xB, x_a, fB)
-    xA = focus_translation(xA, x_a, fA)
+    fB = fA = fA2 = None
+    if focus:
+        xB, fB = decode(G_AB, c1, z1, g).split(3, 1)
+        xA, fA = decode(G_BA, c2, alpha * z2, g).split(3, 1)
+        xB = focus_translation(xB, x_a, fB)
+        xA = focus_translation(xA, x_a, fA)
+    else:
+        xB = decode(G_AB, c1, z1, g)
+        xA = decode(G_BA, c2, alpha * z2, g)
     if with_recon:
         c4, s4 = gen_encode(G_AB, x_b, g)
         out["x_A_recon"] = decode(G_BA, c2, s2, g)[:, :3]
         out["x_B_recon"] = decode(G_AB, c4, s4, g)[:, :3]
     c3 = content_encode(G_BA, xB, g)
-    xA2, fA2 = decode(G_BA, c3, z3, g).split(3, 1)
-    xA2 = focus_translation(xA2, xB, fA2)
+    if focus:
+        xA2, fA2 = decode(G_BA, c3, z3, g).split(3, 1)
+        xA2 = focus_translation(xA2, xB, fA2)
+    else:
+        xA2 = decode(G_BA, c3, z3, g)
     out.update(x_B_fake=xB, x_A_fake=xA, x_A2_fake=xA2, f_B=fB, f_A=fA, f_A2=fA2,
                pair_A1=torch.cat((x_a, xA), 1), pair_A2=torch.cat((x_a, xA2), 1),
                c_1=c1, c_2=c2, c_3=c3, s_2=s2)
@@ -575,14 +586,15 @@ def gen_losses(nets: Dict[str, Params], x_a, x_b, z, hp):
                           lsgan(dis_forward(nets["dis_2"], fw["pair_A2"], d), 0.0)
     total = hp["gan_w"] * L["loss_gen_adv_A"] + hp["gan_w"] * L["loss_gen_adv_B"] + \
             hp["gan_cw"] * L["loss_gen_adv_2"]
-    sB, dB = focus_losses(fw["f_B"], hp)
-    sA, dA = focus_losses(fw["f_A"], hp)
-    sA2, dA2 = focus_losses(fw["f_A2"], hp)
-    L["loss_gen_focus_B_size"], L["loss_gen_focus_B_digit"] = sB, dB
-    L["loss_gen_focus_A_size"], L["loss_gen_focus_A_digit"] = sA, dA
-    L["loss_gen_focus_A2_size"], L["loss_gen_focus_A2_digit"] = sA2, dA2
-    B, _, H, W = x_a.shape
-    total = total + hp["focus_loss"] * (sB + dB + sA + dA + sA2 + dA2) / H / W / B / 3
+    if hp["focus_loss"] > 0:      # trainer.py:145-161 (the non-focus branch sets none of the six focus attributes)
+        sB, dB = focus_losses(fw["f_B"], hp)
+        sA, dA = focus_losses(fw["f_A"], hp)
+        sA2, dA2 = focus_losses(fw["f_A2"], hp)
+        L["loss_gen_focus_B_size"], L["loss_gen_focus_B_digit"] = sB, dB
+        L["loss_gen_focus_A_size"], L["loss_gen_focus_A_digit"] = sA, dA
+        L["loss_gen_focus_A2_size"], L["loss_gen_focus_A2_digit"] = sA2, dA2
+        B, _, H, W = x_a.shape
+        total = total + hp["focus_loss"] * (sB + dB + sA + dA + sA2 + dA2) / H / W / B / 3
     L["loss_idt_A"] = torch.mean(torch.abs(fw["x_A_recon"] - x_a))
     L["loss_idt_B"] = torch.mean(torch.abs(fw["x_B_recon"] - x_b))
     total = total + hp["recon_x_w"] * L["loss_idt_A"] + hp["recon_x_w"] * L["loss_idt_B"]

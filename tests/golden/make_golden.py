@@ -146,11 +146,12 @@ def run_step_fixture(cfg, B, H, W, seed, fname, store_tensors):
         c2, s2 = tr.gen_BA.encode(xa)
         xB4 = tr.gen_AB.decode(c1, zd[0])
         xA4 = tr.gen_BA.decode(c2, cfg["alpha"] * zd[1])
-        xB = tr.focus_translation(xB4[:, :3], xa, xB4[:, 3:])
-        xA = tr.focus_translation(xA4[:, :3], xa, xA4[:, 3:])
+        focus = cfg["focus_loss"] > 0      # trainer.py:107-121: focus branch (image + mask) or the decoder output itself
+        xB = tr.focus_translation(xB4[:, :3], xa, xB4[:, 3:]) if focus else xB4
+        xA = tr.focus_translation(xA4[:, :3], xa, xA4[:, 3:]) if focus else xA4
         c3, _ = tr.gen_BA.encode(xB)
         xA24 = tr.gen_BA.decode(c3, zd[2])
-        xA2 = tr.focus_translation(xA24[:, :3], xB, xA24[:, 3:])
+        xA2 = tr.focus_translation(xA24[:, :3], xB, xA24[:, 3:]) if focus else xA24
         dA = tr.dis_A(xA)
         d2 = tr.dis_2(torch.cat((xa, xA2), 1))
         fw = {"c_1": c1, "c_2": c2, "s_2": s2, "dec_AB_c1_z1": xB4, "dec_BA_c2_z2": xA4,
@@ -178,13 +179,14 @@ def run_step_fixture(cfg, B, H, W, seed, fname, store_tensors):
     # chained gen_update on the updated discriminators (train.py:71-74 order)
     with RandnQueue(zd[3:6]):
         tr.gen_update(xa, xb, cfg)
-    meta["seq_losses"] = {n: float(getattr(tr, n).detach()) for n in LOSS_NAMES_GEN}
+    meta["seq_losses"] = {n: float(getattr(tr, n).detach()) for n in LOSS_NAMES_GEN if hasattr(tr, n)}
     # gen_update from the initial weights (z_1..z_3 = z[3:6])
     tr, _ = fresh()
     with RandnQueue(zd[3:6]):
         tr.gen_update(xa, xb, cfg)
     for n in LOSS_NAMES_GEN:
-        meta["losses"][n] = float(getattr(tr, n).detach())
+        if hasattr(tr, n):      # (the non-focus branch sets none of the six focus attributes, trainer.py:145)
+            meta["losses"][n] = float(getattr(tr, n).detach())
     for name in ("gen_AB", "gen_BA"):
         for k, p in getattr(tr, name).named_parameters():
             meta["grad_stats"]["gen_update/%s/%s" % (name, k)] = tstats(p.grad)
@@ -315,7 +317,7 @@ def key_list():
     json.dump(order, open(os.path.join(HERE, "param_order.json"), "w"), indent=0)
 
 
-if __name__ == "__main__" and "--checkpoint-only" not in sys.argv and "--loop-only" not in sys.argv:
+if __name__ == "__main__" and "--checkpoint-only" not in sys.argv and "--loop-only" not in sys.argv and "--plain-only" not in sys.argv:
     torch.manual_seed(0)
     op_vectors()
     key_list()
@@ -326,6 +328,30 @@ if __name__ == "__main__" and "--checkpoint-only" not in sys.argv and "--loop-on
     smooth = base_config(); smooth["focus_epsilon"] = 0.5
     run_step_fixture(smooth, 1, 64, 64, 2, "step_full_64_smooth", False)
     print("golden fixtures written to", HERE)
+
+
+def plain_config():
+    """the non-focus configuration (trainer.py:117-121,129-130,266-276: the paper's ablation): focus_loss 0 and a 3-channel decoder"""
+    cfg = reduced_config()
+    cfg["focus_loss"] = 0
+    cfg["gen"]["output_dim"] = 3
+    return cfg
+
+
+def plain_fixture():
+    run_step_fixture(plain_config(), 2, 64, 64, 3, "step_reduced_64_plain", True)
+    # sample() of the non-focus branch (trainer.py:216-230,238-245): 7 outputs, float32 reference
+    cfg = plain_config()
+    tr = ref_trainer.aclgan_Trainer(cfg)
+    fill_reference(tr, cfg)
+    x_a, x_b, z = seeded_inputs(2, 64, 64, 3)
+    tr.z_1, tr.z_2, tr.z_3 = z[0], z[1], z[2]
+    with torch.no_grad():
+        outs = tr.sample(x_a, x_b)
+    names = ["x_A", "x_A_fake", "x_B_fake", "x_A2_fake", "x_A_recon", "x_B", "x_B_recon"]
+    assert len(outs) == 7
+    np.savez_compressed(os.path.join(HERE, "sample_reduced_64_plain.npz"), **{n: o.numpy() for n, o in zip(names, outs)})
+    print("plain sample fixture:", {n: tuple(o.shape) for n, o in zip(names, outs)})
 
 
 def checkpoint_fixture():
@@ -455,3 +481,5 @@ if __name__ == "__main__" and "--checkpoint-only" in sys.argv:
     checkpoint_fixture()
 if __name__ == "__main__" and "--loop-only" in sys.argv:
     loop_fixture()
+if __name__ == "__main__" and "--plain-only" in sys.argv:
+    plain_fixture()

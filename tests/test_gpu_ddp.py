@@ -86,7 +86,7 @@ def test_bench_two_ranks_share_one_gpu():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ACLGAN_BENCH_FORCE_DIST", "ACLGAN_DDP_OVERLAP"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64", "--batch", "2",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-launch-floor"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)

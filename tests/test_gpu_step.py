@@ -80,7 +80,7 @@ def test_state_dict_surface(T):
     assert abs(float(wd.std()) - 0.02) < 1e-3
 
 
-@pytest.mark.parametrize("fix", ["step_reduced_64", "step_full_64"])
+@pytest.mark.parametrize("fix", ["step_reduced_64", "step_full_64", "step_reduced_64_plain"])
 def test_forward_matches_reference(T, fix):
     """encode / decode / discriminator forward vs the fp64 reference tensors (north star: 1e-3 rel)."""
     meta, data = _load(fix)
@@ -100,11 +100,12 @@ def test_forward_matches_reference(T, fix):
     c2, s2 = tr.gen_BA.encode(x_a); chk("c_2", c2); chk("s_2", s2)
     xB4 = tr.gen_AB.decode(c1, z[0]); chk("dec_AB_c1_z1", xB4)
     xA4 = tr.gen_BA.decode(c2, cfg["alpha"] * z[1]); chk("dec_BA_c2_z2", xA4)
-    xB = tr.focus_translation(xB4[:, :3], x_a, xB4[:, 3:]); chk("x_B_fake", xB)
-    xA = tr.focus_translation(xA4[:, :3], x_a, xA4[:, 3:]); chk("x_A_fake", xA)
+    focus = cfg["focus_loss"] > 0      # the _plain fixture: non-focus configuration, the 3-channel decoder output is the image
+    xB = tr.focus_translation(xB4[:, :3], x_a, xB4[:, 3:]) if focus else xB4; chk("x_B_fake", xB)
+    xA = tr.focus_translation(xA4[:, :3], x_a, xA4[:, 3:]) if focus else xA4; chk("x_A_fake", xA)
     c3, _ = tr.gen_BA.encode(xB); chk("c_3", c3)
     xA24 = tr.gen_BA.decode(c3, z[2])
-    xA2 = tr.focus_translation(xA24[:, :3], xB, xA24[:, 3:]); chk("x_A2_fake", xA2)
+    xA2 = tr.focus_translation(xA24[:, :3], xB, xA24[:, 3:]) if focus else xA24; chk("x_A2_fake", xA2)
     dA = tr.dis_A(xA)
     for s in range(3):
         chk("dis_A_xA_s%d" % s, dA[s])
@@ -127,7 +128,8 @@ def _grads_by_name(tr, nets):
 
 
 @pytest.mark.parametrize("fix,ltol,gtol", [("step_reduced_64_smooth", 1e-3, 1e-2), ("step_full_64_smooth", 1e-3, 1e-2),
-                                            ("step_reduced_64", 1e-3, 1e-1), ("step_full_64", 1e-3, 1e-1)])
+                                            ("step_reduced_64", 1e-3, 1e-1), ("step_full_64", 1e-3, 1e-1),
+                                            ("step_reduced_64_plain", 1e-3, 1e-2)])      # non-focus configuration (trainer.py:117-121,266-276)
 def test_update_steps_match_reference(T, fix, ltol, gtol):
     """dis_update and gen_update (each from the fixture's initial weights) vs the fp64 reference:
     the 16 losses (1e-3 rel; 'size' losses 2e-2, a 200x-cancelling sum squared), every gradient
@@ -169,7 +171,7 @@ def test_update_steps_match_reference(T, fix, ltol, gtol):
     # sit on the wrong side of zero relative to the oracle is fixed for a given build: the comparison is repeatable up to the
     # ~1e-7 atomics noise of the default backward (deterministic mode: exactly).  The bound covers the mask flips themselves
     # (they depend on the kernels' summation order, i.e. they change when a kernel's tiling changes, not between runs).
-    etol = ETOL_SMOOTH if fix.endswith("smooth") else ETOL_DEFAULT
+    etol = ETOL_SMOOTH if fix.endswith(("smooth", "plain")) else ETOL_DEFAULT
     seen = []
 
     def l2ok(g, ref, key):
@@ -425,6 +427,24 @@ def test_resume_from_reference_written_checkpoint(T, tmp_path):
     assert mine["dis"]["param_groups"][0]["params"] == ref_opt["dis"]["param_groups"][0]["params"]
     mg = torch.load(os.path.join(out, "gen_00000008.pt"), map_location="cpu")
     assert list(mg["AB"].keys()) == list(ref_gen["AB"].keys())
+
+
+def test_sample_non_focus_configuration(T):
+    """sample() with focus_loss 0 / gen.output_dim 3 (trainer.py:216-230,238-245): the reference's 7-tuple, values against the
+    reference's own outputs -- including its x_B_recon of B x B images (it encodes the whole batch x_b inside the per-image loop)."""
+    meta, data = _load("step_reduced_64_plain")
+    ref = np.load(os.path.join(GOLDEN, "sample_reduced_64_plain.npz"))
+    cfg = meta["config"]
+    tr = _make(T, cfg, O.test_nets(cfg, 0))
+    x_a, x_b = torch.from_numpy(data["x_a"]), torch.from_numpy(data["x_b"])
+    tr.z_1, tr.z_2, tr.z_3 = (torch.from_numpy(data["z%d" % i]).cuda() for i in range(3))
+    outs = tr.sample(x_a, x_b)
+    names = ["x_A", "x_A_fake", "x_B_fake", "x_A2_fake", "x_A_recon", "x_B", "x_B_recon"]
+    assert len(outs) == 7
+    for n, o in zip(names, outs):
+        r = torch.from_numpy(ref[n])
+        assert tuple(o.shape) == tuple(r.shape), (n, o.shape, r.shape)
+        assert _rel(o, r) < 1e-3, n
 
 
 def test_errors_surface_as_exceptions_not_aborts(T):
