@@ -200,8 +200,11 @@ class GpuImageLoader:
     def __init__(self, dataset, batch_size, train, new_size, height, width, num_workers=4, crop=True, device="cuda", rank=0, world_size=1,
                  shard_seed=0):
         """rank / world_size (data parallel, not in the reference): batch_size is PER RANK; every epoch all ranks draw the SAME
-        permutation (generator seeded shard_seed + epoch) and rank r takes slice r of each global batch of world_size * batch_size
-        samples -- disjoint shards, every sample at most once per epoch, equal batch counts on all ranks."""
+        permutation (generator seeded from shard_seed and the epoch) and rank r takes slice r of each global batch of world_size *
+        batch_size samples -- disjoint shards, every sample at most once per epoch, equal batch counts on all ranks.
+        shard_seed must be equal on all ranks and DIFFERENT for the A and the B loader (get_all_data_loaders derives both from the
+        user's torch seed): with one seed for both, equally long folders (selfie2anime: 3400 / 3400) would pair A[i] with B[i] at
+        every step of every epoch, where the reference's two DataLoaders shuffle independently (utils.py:91-100)."""
         self.source, self.batch_size, self.train = dataset, batch_size, train
         self.rank, self.world, self.shard_seed, self._epoch = int(rank), max(1, int(world_size)), int(shard_seed), 0
         assert 0 <= self.rank < self.world
@@ -220,10 +223,15 @@ class GpuImageLoader:
         elif self.world == 1:
             order = torch.randperm(n).tolist()          # the default generator, like DataLoader(shuffle=True)
         else:
-            order = torch.randperm(n, generator=torch.Generator().manual_seed(self.shard_seed + self._epoch)).tolist()
+            order = torch.randperm(n, generator=torch.Generator().manual_seed((self.shard_seed + 1000003 * self._epoch) % (2 ** 63 - 1))).tolist()
         self._epoch += 1
         gb = self.batch_size * self.world
         return [order[b * gb + self.rank * self.batch_size: b * gb + (self.rank + 1) * self.batch_size] for b in range(len(self))]
+
+    def set_epoch(self, epoch):
+        """resume support: the next pass draws the permutation of epoch `epoch` (train.py derives it from the restored iteration count,
+        so a resumed data-parallel run does not replay the permutations of epochs 0, 1, ...)"""
+        self._epoch = int(epoch)
 
     def __iter__(self):
         batches = self.batch_indices()
@@ -249,19 +257,37 @@ class _TransformedView:
 
 
 def get_data_loader_folder(input_folder, batch_size, train, new_size=None, height=256, width=256, num_workers=4, crop=True,
-                           datakind='', device="cuda", rank=0, world_size=1):
+                           datakind='', device="cuda", rank=0, world_size=1, shard_seed=0):
     """utils.py:91-100"""
-    return GpuImageLoader(ImageFolder(input_folder), batch_size, train, new_size, height, width, num_workers, crop, device, rank, world_size)
+    return GpuImageLoader(ImageFolder(input_folder), batch_size, train, new_size, height, width, num_workers, crop, device, rank, world_size, shard_seed)
 
 
 def get_data_loader_list(root, file_list, batch_size, train, new_size=None, height=256, width=256, num_workers=4, crop=True,
-                         datakind='', device="cuda", rank=0, world_size=1):
+                         datakind='', device="cuda", rank=0, world_size=1, shard_seed=0):
     """utils.py:78-89"""
-    return GpuImageLoader(ImageFilelist(root, file_list), batch_size, train, new_size, height, width, num_workers, crop, device, rank, world_size)
+    return GpuImageLoader(ImageFilelist(root, file_list), batch_size, train, new_size, height, width, num_workers, crop, device, rank, world_size, shard_seed)
 
 
-def get_all_data_loaders(conf, device="cuda", rank=0, world_size=1):
-    """utils.py:43-76: (train_a, train_b, test_a, test_b); rank / world_size shard the TRAIN loaders (see GpuImageLoader)"""
+def shard_base_seed(world_size=1):
+    """the seed the sharded loaders derive their per-epoch permutations from: the user's torch seed (torch.manual_seed / the process
+    default), agreed across ranks -- rank 0's value is broadcast when a process group exists (ranks that never called
+    torch.manual_seed hold different random default seeds)"""
+    seed = int(torch.initial_seed()) % (2 ** 62)
+    if world_size > 1:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            box = [seed]
+            dist.broadcast_object_list(box, src=0)
+            seed = int(box[0])
+    return seed
+
+
+def get_all_data_loaders(conf, device="cuda", rank=0, world_size=1, base_seed=None):
+    """utils.py:43-76: (train_a, train_b, test_a, test_b); rank / world_size shard the TRAIN loaders (see GpuImageLoader); the A and B
+    train loaders get different shard seeds derived from base_seed (default: shard_base_seed(world_size))"""
+    if base_seed is None:
+        base_seed = shard_base_seed(world_size)
+    seed_of = {"a": (2 * base_seed + 1) % (2 ** 62), "b": (2 * base_seed + 0x5bd1e995) % (2 ** 62)}
     batch_size, num_workers = conf['batch_size'], conf['num_workers']
     if 'new_size' in conf:
         new_size_a = new_size_b = conf['new_size']
@@ -272,11 +298,11 @@ def get_all_data_loaders(conf, device="cuda", rank=0, world_size=1):
     if 'data_root' in conf:
         r = conf['data_root']
         mk = lambda sub, train, ns, h, w: get_data_loader_folder(os.path.join(r, sub), batch_size, train, ns, h, w, num_workers, True, datakind, device,
-                                                                 rank if train else 0, world_size if train else 1)
+                                                                 rank if train else 0, world_size if train else 1, seed_of[sub[-1].lower()])
         return (mk('trainA', True, new_size_a, height, width), mk('trainB', True, new_size_b, height, width),
                 mk('testA', False, new_size_a, new_size_a, new_size_a), mk('testB', False, new_size_b, new_size_b, new_size_b))
     mk = lambda f, l, train, ns, h, w: get_data_loader_list(conf[f], conf[l], batch_size, train, ns, h, w, num_workers, True, datakind, device,
-                                                            rank if train else 0, world_size if train else 1)
+                                                            rank if train else 0, world_size if train else 1, seed_of[f[-1].lower()])
     return (mk('data_folder_train_a', 'data_list_train_a', True, new_size_a, height, width),
             mk('data_folder_train_b', 'data_list_train_b', True, new_size_b, height, width),
             mk('data_folder_test_a', 'data_list_test_a', False, new_size_a, new_size_a, new_size_a),

@@ -148,3 +148,39 @@ def test_inference_script_host_helpers(tmp_path):
     fg, bg, m = torch.rand(2, 3, 4, 4) * 2 - 1, torch.rand(2, 3, 4, 4) * 2 - 1, torch.rand(2, 1, 4, 4) * 2 - 1
     mm = ((m + 1) / 2).repeat(1, 3, 1, 1)
     assert torch.allclose(script.focus_translation(fg, bg, m), fg * mm + bg * (1 - mm), atol=1e-6)
+
+
+def test_sharded_loaders_of_the_two_domains_shuffle_independently(tmp_path):
+    """data-parallel epochs: ranks agree on one permutation per loader and epoch, the A and the B loader draw DIFFERENT ones (with one
+    shared seed, equally long folders would pair A[i] with B[i] at every step), the permutation follows the user's torch seed, and a
+    resumed run continues with the next epoch's permutation instead of replaying epoch 0."""
+    from PIL import Image
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd import data as D
+    for sub in ("trainA", "trainB", "testA", "testB"):
+        os.makedirs(tmp_path / sub)
+        for i in range(12):
+            Image.new("RGB", (8, 8), (i, i, i)).save(tmp_path / sub / ("%02d.png" % i))
+    conf = dict(batch_size=2, num_workers=1, new_size=8, crop_image_height=8, crop_image_width=8, data_root=str(tmp_path))
+
+    def order(loader):
+        return [i for b in loader.batch_indices() for i in b]
+
+    torch.manual_seed(1234)
+    a0, b0, _, _ = D.get_all_data_loaders(conf, device="cpu", rank=0, world_size=2)
+    a1, b1, _, _ = D.get_all_data_loaders(conf, device="cpu", rank=1, world_size=2)
+    ea0, ea1, eb0 = order(a0), order(a1), order(b0)
+    assert sorted(ea0 + ea1) == list(range(12)) and not set(ea0) & set(ea1)      # disjoint shards of one permutation
+    full_a = [i for pair in zip(*[iter(ea0)] * 2, *[iter(ea1)] * 2) for i in pair]
+    eb1 = order(b1)
+    full_b = [i for pair in zip(*[iter(eb0)] * 2, *[iter(eb1)] * 2) for i in pair]
+    assert sorted(full_b) == list(range(12)) and full_a != full_b                 # A and B are not paired index by index
+    second = order(a0)
+    assert second != ea0                                                          # next epoch, next permutation
+    torch.manual_seed(1234)
+    a0r, _, _, _ = D.get_all_data_loaders(conf, device="cpu", rank=0, world_size=2)
+    a0r.set_epoch(1)
+    assert order(a0r) == second                                                   # resume at epoch 1 = what the uninterrupted run drew
+    torch.manual_seed(99)
+    a0s, _, _, _ = D.get_all_data_loaders(conf, device="cpu", rank=0, world_size=2)
+    assert order(a0s) != ea0                                                      # the user's seed matters

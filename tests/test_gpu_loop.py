@@ -8,8 +8,8 @@ from test_loop_cpu import load_loop
 
 pytestmark = pytest.mark.gpu
 
-LTOL = 2e-3          # losses, relative (6 chained fp32 Adam steps against the float64 reference)
-LTOL_SIZE = 2e-2     # the *_size losses: a cancelling sum, squared
+LTOL = 1e-4          # losses, relative (6 chained fp32 Adam steps against the float64 reference; measured worst 2.2e-6)
+LTOL_SIZE = 5e-3     # the *_size losses: a cancelling sum, squared
 
 
 def run(cfg, xa, xb, zs):

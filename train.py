@@ -107,6 +107,9 @@ def main():
                      "to train on synthetic U(-1,1) batches" % (folder, opts.config))
         from aclgan_amd.data import get_all_data_loaders
         train_loader_a, train_loader_b, _, _ = get_all_data_loaders(config, device="cuda:%d" % local_rank, rank=rank, world_size=world)   # train.py:43
+        if iterations and len(train_loader_a) and len(train_loader_b):           # resumed: do not replay the permutations of the epochs already seen
+            done = iterations // min(len(train_loader_a), len(train_loader_b))
+            train_loader_a.set_epoch(done); train_loader_b.set_epoch(done)
         epoch = lambda: zip(train_loader_a, train_loader_b)                      # train.py:66
         if is_main:
             print("data: %d / %d training images, device input pipeline, %d rank(s) x batch %d" % (len(train_loader_a.source), len(train_loader_b.source), world, B))
