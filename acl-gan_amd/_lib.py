@@ -71,6 +71,8 @@ SIGNATURES = {
     "aclgan_version": (ci, []),
     "aclgan_launch_count": (C.c_longlong, []),
     "aclgan_gemm_slices_f32": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "aclgan_winograd_filter_frag": (ci, [vp, vp, ci, ci, ci, vp]),
+    "aclgan_conv3x3_winograd_fused": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "aclgan_gemm_slices_x3_scratch_bytes": (sz, [ci, ci, ci, ci]),
     "aclgan_gemm_slices_x3": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "aclgan_set_deterministic": (ci, [ci]),

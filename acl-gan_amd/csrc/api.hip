@@ -68,6 +68,21 @@ int aclgan_gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, in
     return gemm_slices_f32(A, Bm, Cm, T, K, N, nslices, 0, (hipStream_t)stream);
 }
 
+int aclgan_winograd_filter_frag(const float* w, float* Uf, int Co, int Ci, int flip, void* stream) {
+    ACL_REQUIRE(w && Uf && Co > 0 && Ci > 0, "winograd_filter_frag: bad argument");
+    ACL_REQUIRE((flip ? Co : Ci) % 16 == 0 && (flip ? Ci : Co) % 64 == 0, "winograd_filter_frag: the K side must be a multiple of 16, the row side of 64");
+    return wino_fused_filter(w, Uf, Co, Ci, flip, (hipStream_t)stream);
+}
+int aclgan_conv3x3_winograd_fused(const float* x, const float* Uf, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int act, int reflect,
+                                  int accumulate, float* stats, void* stream) {
+    ACL_REQUIRE(x && Uf && y && B > 0, "conv3x3_winograd_fused: null argument");
+    const int old = set_wino_fused(wino_fused_mode() ? wino_fused_mode() : 1);      // (the entry point IS the fused kernel, whatever the step's switch says)
+    const int rc = wino_fused_launch(B, H, W, Cin, Cout, x, Uf, bias, y, act, accumulate, reflect, (float2*)stats, (hipStream_t)stream);
+    set_wino_fused(old);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("conv3x3_winograd_fused: shape not eligible (H, W multiples of 4, Cin of 16, Cout of 64, no tanh)");
+    return rc;
+}
+
 int aclgan_conv2d_fwd(const aclgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* stream) {
     ConvGeom g;
     int rc = make_geom(d, &g);

@@ -17,6 +17,7 @@
 //     discarded by dis_opt.zero_grad, trainer.py:248); the two style-encoder passes whose output
 //     is dropped (trainer.py:103,125) are skipped.
 #include "common.h"
+#include <dlfcn.h>
 
 #include <functional>
 #include <map>
@@ -77,8 +78,51 @@ struct TapeOp {
 
 using namespace aclgan;
 
+// ---- roctx ranges per network pass (tracing): ACLGAN_ROCTX=1 wraps every forward pass of a network ("gen_AB.encode#1",
+// "gen_BA.decode#2", "dis_2.forward#1", ...) and the backward closures it recorded ("bwd:gen_BA.decode#2") in roctx ranges, so that a
+// rocprofv3 --marker-trace --kernel-trace run can be cut by pass.  The marker library is opened lazily (no link-time dependency).
+namespace aclgan {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+    Roctx() {
+        const char* env = getenv("ACLGAN_ROCTX");
+        if (!env || !atoi(env)) return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) { on = true; return; }
+        }
+    }
+    static Roctx& get() { static Roctx r; return r; }
+};
+}  // namespace aclgan
+
 struct aclgan_ctx {
     aclgan_arch arch;
+    // roctx pass labels: index into pass_names of the pass being built (-1: none); every tape closure remembers the pass that pushed it
+    std::vector<std::string> pass_names;
+    std::vector<int> tape_pass;
+    std::map<std::string, int> pass_count;
+    int cur_pass = -1;
+    int pass_begin(const char* net, const char* what) {
+        if (!Roctx::get().on || dry) return -1;
+        const std::string base = std::string(net) + "." + what;
+        const int n = ++pass_count[base];
+        pass_names.push_back(base + "#" + std::to_string(n));
+        const int prev = cur_pass;
+        cur_pass = (int)pass_names.size() - 1;
+        Roctx::get().push(pass_names.back().c_str());
+        return prev;
+    }
+    void pass_end(int prev) {
+        if (!Roctx::get().on || dry) return;
+        Roctx::get().pop();
+        cur_pass = prev;
+    }
     Group groups[2];
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -190,6 +234,7 @@ struct aclgan_ctx {
         for (Act* a : acts) delete a;
         acts.clear();
         tape.clear();
+        tape_pass.clear(); pass_names.clear(); pass_count.clear(); cur_pass = -1;
         top = 0;
         top2 = 0;
         keep_total = 0;
@@ -233,6 +278,7 @@ struct aclgan_ctx {
             for (const auto& g : grads)
                 if (g.first && g.second > 0 && op.ng < 4) { op.goff[op.ng] = g.first - groups[trained].grad; op.gnum[op.ng] = g.second; ++op.ng; }
         tape.push_back(std::move(op));
+        tape_pass.push_back(cur_pass);
     }
     PW pw(int group, int net, const std::string& key, bool with_bias = true) const;
     int64_t numel_of(int group, int net, const std::string& key) const;
@@ -242,7 +288,6 @@ struct aclgan_ctx {
 
 namespace aclgan {
 
-static const char* NET_NAMES[5] = {"gen_AB", "gen_BA", "dis_A", "dis_B", "dis_2"};
 
 #define RUN(expr)                                  \
     do {                                           \
@@ -314,6 +359,8 @@ static void build_dis(Group& g, const std::string& net, int input_dim, const acl
     }
 }
 
+static const char* NET_NAMES[5] = {"gen_AB", "gen_BA", "dis_A", "dis_B", "dis_2"};
+
 }  // namespace aclgan
 
 const float* aclgan_ctx::param(int group, int net, const std::string& key) const {
@@ -356,6 +403,13 @@ static size_t keepv_budget() {
     if (!v) { const char* e = getenv("ACLGAN_KEEPV_BUDGET_GB"); const double gb = e ? atof(e) : 64.0; v = (size_t)(gb * 1073741824.0) + 1; }
     return v;
 }
+
+// roctx range of one forward pass of a network (ACLGAN_ROCTX=1); closes on every return path
+struct PassScope {
+    aclgan_ctx& c; int prev;
+    PassScope(aclgan_ctx& c_, int net, const char* what) : c(c_), prev(c_.pass_begin(NET_NAMES[net], what)) {}
+    ~PassScope() { c.pass_end(prev); }
+};
 
 struct NormSpec {
     int kind = ACLGAN_NORM_NONE;
@@ -547,6 +601,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
 
 // ContentEncoder.forward (networks.py:230-245)
 static int content_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
+    PassScope pass(c, net, "encode");
     const aclgan_arch& a = c.arch;
     char buf[160];
     NormSpec in_; in_.kind = ACLGAN_NORM_IN;
@@ -607,6 +662,7 @@ static int dense(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int O, int a
 
 // StyleEncoder.forward (networks.py:212-228)
 static int style_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
+    PassScope pass(c, net, "style");
     const aclgan_arch& a = c.arch;
     char buf[160];
     NormSpec none;
@@ -646,6 +702,7 @@ static int style_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
 
 // AdaINGen.decode (networks.py:147-163) + Decoder.forward (networks.py:247-264)
 static int decode(aclgan_ctx& c, int net, bool train, Act* content, Act* style, Act** out) {
+    PassScope pass(c, net, "decode");
     const aclgan_arch& a = c.arch;
     char buf[160];
     const int C = content->C, nr = a.gen_n_res, nad = 2 * C * 2 * nr;
@@ -692,6 +749,7 @@ static int decode(aclgan_ctx& c, int net, bool train, Act* content, Act* style, 
 
 // MsImageDis.forward (networks.py:50-57)
 static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<Act*>* outs) {
+    PassScope pass(c, net, "forward");
     const aclgan_arch& a = c.arch;
     char buf[160];
     NormSpec none;
@@ -879,13 +937,22 @@ static int run_tape(aclgan_ctx& c) {
             else done_at[first[b]].push_back(b);
         }
     }
+    const bool marks = Roctx::get().on && !c.dry && c.tape_pass.size() == n;
+    int open = -1;
     for (size_t i = n; i-- > 0;) {
-        CHK(c.tape[i].fn());
+        if (marks && c.tape_pass[i] != open) {      // consecutive closures of one forward pass = one backward range
+            if (open >= 0) Roctx::get().pop();
+            open = c.tape_pass[i];
+            if (open >= 0) Roctx::get().push(("bwd:" + c.pass_names[open]).c_str());
+        }
+        const int rc_i = c.tape[i].fn();
+        if (rc_i) { if (marks && open >= 0) Roctx::get().pop(); return rc_i; }
         if (buckets && !done_at[i].empty()) {
             CHK(c.side_join());             // a bucket handed to the all-reduce must hold its side-stream weight gradients too
             for (int b : done_at[i]) fire_bucket(c, b);
         }
     }
+    if (marks && open >= 0) Roctx::get().pop();
     return c.side_join();
 }
 

@@ -118,6 +118,16 @@ long long aclgan_launch_count(void);
  * 3x3 convolutions (networks.py:297-310) spends its MFMA time in, exposed alone so that bench.py can time the step's dominant
  * kernel with HIP events and tests can check it against torch.bmm.  K % 16 == 0. */
 int aclgan_gemm_slices_f32(const float* A, const float* B, float* C, int T, int K, int N, int nslices, void* stream);
+/* Round 4 (csrc/conv_wino_fused.hip): ReflectionPad2d(1) + Conv2d(3x3) of the ResBlocks (networks.py:297-310, 366-370) as ONE launch -- Winograd
+ * F(4x4,3x3) with the input transform, the 36 frequency GEMMs and the output transform (+ bias, activation, per-tile normalisation partials) fused:
+ * the step's dominant kernel, exposed alone so that bench.py can time it with HIP events and tests can check it against the oracle.
+ * aclgan_winograd_filter_frag: Uf (36 * Co * Ci floats) <- G g G^T of the OHWI filter w in MFMA-fragment order (flip != 0: the flipped, transposed
+ * filter of the input gradient; then Uf is indexed [cin rows][cout k]).  The step computes it once per update and filter.
+ * aclgan_conv3x3_winograd_fused: y[B][H][W][Cout] (+)= act(conv(x[B][H][W][Cin]) + bias); reflect != 0: reflection padding 1, else zero padding;
+ * stats (optional): [B][H/4 * W/4][Cout] (mean, M2) pairs of the 4x4 output tiles.  H, W % 4 == 0, Cin % 16 == 0, Cout % 64 == 0, act != tanh. */
+int aclgan_winograd_filter_frag(const float* w, float* Uf, int Co, int Ci, int flip, void* stream);
+int aclgan_conv3x3_winograd_fused(const float* x, const float* Uf, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int act, int reflect,
+                                  int accumulate, float* stats, void* stream);
 /* The same product with fp32 accuracy on the bf16 matrix cores (round 3, csrc/gemm_bf16x3.hip): each fp32 operand is split EXACTLY into
  * three bf16 numbers (h + m + l), six of the nine cross products (everything above 2^-24 of the product) are accumulated in fp32 by
  * v_mfma_f32_32x32x16_bf16.  This entry point splits A and B into `scratch` (aclgan_gemm_slices_x3_scratch_bytes) and runs the kernel; the

@@ -15,7 +15,13 @@ tr = aclgan_Trainer(cfg, compute_dtype=dtype)
 g = torch.Generator().manual_seed(1)
 x_a = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda(); x_b = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
 z = [torch.randn(B, 8, 1, 1, generator=g) for _ in range(3)]
+from aclgan_amd import _lib as L
+n0 = L.lib.aclgan_launch_count()
 for _ in range(steps):
     tr.dis_update(x_a, x_b, cfg, z=z); tr.gen_update(x_a, x_b, cfg, z=z)
 torch.cuda.synchronize()
-print("probe_step: %d steps %s %dx%d B=%d done" % (steps, dtype, S, S, B))
+lps = (L.lib.aclgan_launch_count() - n0) / float(steps)
+if os.environ.get("PROBE_STEP_JSON"):
+    import json
+    json.dump({"launches_per_step": lps, "dtype": dtype, "size": S, "batch": B}, open(os.environ["PROBE_STEP_JSON"], "w"))
+print("probe_step: %d steps %s %dx%d B=%d done, %.1f library launches per step" % (steps, dtype, S, S, B, lps))

@@ -7,7 +7,10 @@
 
 Sums the counter over every kernel the library launched (torch's own init / fill kernels excluded), divides by the number of steps,
 applies the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read: x2) and merges
-{key: {"bytes_per_step", "fetch_bytes", "write_bytes", ...}} into out.json (default profiles/r03_step_traffic.json).  Counter unit: KiB."""
+{key: {"bytes_per_step", "fetch_bytes", "write_bytes", ...}} into out.json (default profiles/r04_step_traffic.json).  Counter unit: KiB.
+The entry is bound to the build it was measured on: md5 of acl-gan_amd/libaclgan_hip.so, the library's own launch count per step
+(scripts/probe_step.py writes it to $PROBE_STEP_JSON) and the commit ($ACLGAN_HEAD: .git does not travel to the GPU box); bench.py compares
+them with the running library and reports traffic_stale on a mismatch."""
 import json, os, re, sqlite3, sys
 from collections import defaultdict
 
@@ -30,7 +33,7 @@ def load(dbp, counter):
 
 def main():
     fdb, wdb, steps, key = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_step_traffic.json")
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_step_traffic.json")
     summary = sys.argv[6] if len(sys.argv) > 6 else None
     f, w = load(fdb, "FETCH_SIZE"), load(wdb, "WRITE_SIZE")
     fetch = 2.0 * 1024.0 * sum(v[1] for v in f.values()) / steps      # gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x
@@ -38,6 +41,17 @@ def main():
     ent = {"bytes_per_step": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "steps_traced": steps,
            "kernels_per_step": sum(v[0] for v in f.values()) / steps,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/probe_step.py; 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes"}
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        ent["lib_md5"] = hashlib.md5(open(os.path.join(root, "acl-gan_amd", "libaclgan_hip.so"), "rb").read()).hexdigest()
+    except OSError:
+        ent["lib_md5"] = None
+    ent["head"] = os.environ.get("ACLGAN_HEAD")
+    try:
+        ent["launches_per_step"] = json.load(open(os.environ["PROBE_STEP_JSON"]))["launches_per_step"]
+    except Exception:
+        ent["launches_per_step"] = None
     try:
         cur = json.load(open(out))
     except Exception:

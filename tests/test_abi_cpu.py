@@ -114,3 +114,69 @@ def test_step_algorithmic_bytes_dry_run_without_gpu():
     assert L.lib.aclgan_step_algorithmic_bytes(ctx, 2, 8, 256, 256, C.byref(C.c_double())) != 0
     assert L.lib.aclgan_launch_count() == 0                  # a dry run launches nothing
     L.lib.aclgan_ctx_destroy(ctx)
+
+
+def test_host_side_under_address_sanitizer(tmp_path):
+    """SURVEY.md section 5 (sanitizers): the HOST half of the library -- C-ABI argument checks, flat parameter layout, the step scheduler's
+    launch-free dry runs (workspace sizing, algorithmic bytes, the bucket schedule of both updates, focus and non-focus architectures),
+    error paths -- instrumented by AddressSanitizer (`make -C acl-gan_amd/csrc asan`: host-only objects) and driven in a subprocess under
+    the ASan runtime.  Any heap / stack / use-after-free error aborts the child; leaks are not checked (ctypes / Python own the process)."""
+    import glob
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "acl-gan_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j8", "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lib = os.path.join(ROOT, "acl-gan_amd", "libaclgan_hip_asan.so")
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        pytest.skip("no ASan runtime in this image")
+    prog = r'''
+import ctypes as C, sys
+L = C.CDLL(%r)
+class Arch(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("input_dim_a", "input_dim_b", "gen_dim", "gen_mlp_dim", "gen_style_dim", "gen_output_dim", "gen_n_downsample", "gen_n_res",
+                                        "dis_dim", "dis_n_layer", "dis_num_scales")]
+L.aclgan_last_error.restype = C.c_char_p
+L.aclgan_group_numel.restype = C.c_int64
+assert L.aclgan_version() >= 100
+for out_dim, dims in ((4, (64, 256, 64)), (3, (8, 16, 8)), (4, (16, 32, 16))):
+    a = Arch(3, 6, dims[0], dims[1], 8, out_dim, 2, 4, dims[2], 4, 3)
+    ctx = C.c_void_p()
+    assert L.aclgan_ctx_create(C.byref(a), C.byref(ctx)) == 0, L.aclgan_last_error()
+    name = C.create_string_buffer(256); off = C.c_int64(); shp = (C.c_int * 4)(); nd = C.c_int()
+    for grp in (0, 1):
+        for i in range(L.aclgan_tensor_count(ctx, grp)):
+            assert L.aclgan_tensor_info(ctx, grp, i, name, 256, C.byref(off), shp, C.byref(nd)) == 0
+        assert L.aclgan_tensor_info(ctx, grp, 10 ** 6, None, 0, None, None, None) != 0
+        assert L.aclgan_tensor_info(ctx, grp, 0, name, 4, C.byref(off), shp, C.byref(nd)) in (0, -1)      # short name buffer
+        fake = C.c_void_p(0x10000)      # device pointers are never dereferenced on the host
+        assert L.aclgan_bind_params(ctx, grp, fake, fake, fake, fake) == 0
+    for (B, H, W) in ((1, 64, 64), (2, 128, 64), (3, 72, 100)):
+        ws = C.c_size_t()
+        rc = L.aclgan_workspace_bytes(ctx, B, H, W, C.byref(ws))
+        assert (rc == 0 and ws.value > 0) or (H %% 4 or W %% 4), (rc, L.aclgan_last_error())
+        fw = C.c_size_t()
+        L.aclgan_forward_workspace_bytes(ctx, B, H, W, C.byref(fw))
+        v = C.c_double()
+        for which in (0, 1, 2):
+            L.aclgan_step_algorithmic_bytes(ctx, which, B, H, W, C.byref(v))
+        order = (C.c_int * 8192)(); cnt = C.c_int()
+        for grp in (0, 1):
+            for bucket in (4096, 1 << 20):
+                if L.aclgan_set_grad_buckets(ctx, C.c_int64(bucket), None, None) == 0:
+                    L.aclgan_bucket_schedule(ctx, grp, B, H, W, 0, order, 8192, C.byref(cnt))
+                    L.aclgan_bucket_schedule(ctx, grp, B, H, W, 0, order, 1, C.byref(cnt))      # capacity too small: an error code, no overrun
+    assert L.aclgan_workspace_bytes(ctx, 0, 64, 64, C.byref(C.c_size_t())) != 0
+    assert L.aclgan_workspace_bytes(None, 1, 64, 64, C.byref(C.c_size_t())) != 0
+    L.aclgan_ctx_destroy(ctx)
+bad = Arch(3, 3, 64, 256, 8, 4, 2, 4, 64, 4, 3); ctx = C.c_void_p()
+assert L.aclgan_ctx_create(C.byref(bad), C.byref(ctx)) != 0 and L.aclgan_last_error()
+assert L.aclgan_set_tuning(b"no such knob", 1) == -1
+assert L.aclgan_launch_count() == 0
+print("ASAN_CHILD_OK")
+''' % lib
+    env = dict(os.environ)
+    env.update(LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:verify_asan_link_order=0")
+    p = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ASAN_CHILD_OK" in p.stdout and "AddressSanitizer" not in p.stderr, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
