@@ -115,11 +115,15 @@ struct aclgan_ctx {
         pass_names.push_back(base + "#" + std::to_string(n));
         const int prev = cur_pass;
         cur_pass = (int)pass_names.size() - 1;
-        Roctx::get().push(pass_names.back().c_str());
+        // "@N": the library's launch counter when the range opens -- kernels are asynchronous, so a trace is cut by launch ORDER, not by
+        // host time (scripts/rocpd_bypass.py): the range owns the library launches N .. (N of its "~end" marker) - 1
+        Roctx::get().push((pass_names.back() + "@" + std::to_string(g_launches)).c_str());
         return prev;
     }
     void pass_end(int prev) {
         if (!Roctx::get().on || dry) return;
+        Roctx::get().pop();
+        Roctx::get().push(("~end@" + std::to_string(g_launches)).c_str());
         Roctx::get().pop();
         cur_pass = prev;
     }
@@ -941,9 +945,9 @@ static int run_tape(aclgan_ctx& c) {
     int open = -1;
     for (size_t i = n; i-- > 0;) {
         if (marks && c.tape_pass[i] != open) {      // consecutive closures of one forward pass = one backward range
-            if (open >= 0) Roctx::get().pop();
+            if (open >= 0) { Roctx::get().pop(); Roctx::get().push(("~end@" + std::to_string(g_launches)).c_str()); Roctx::get().pop(); }
             open = c.tape_pass[i];
-            if (open >= 0) Roctx::get().push(("bwd:" + c.pass_names[open]).c_str());
+            if (open >= 0) Roctx::get().push(("bwd:" + c.pass_names[open] + "@" + std::to_string(g_launches)).c_str());
         }
         const int rc_i = c.tape[i].fn();
         if (rc_i) { if (marks && open >= 0) Roctx::get().pop(); return rc_i; }
@@ -952,7 +956,7 @@ static int run_tape(aclgan_ctx& c) {
             for (int b : done_at[i]) fire_bucket(c, b);
         }
     }
-    if (marks && open >= 0) Roctx::get().pop();
+    if (marks && open >= 0) { Roctx::get().pop(); Roctx::get().push(("~end@" + std::to_string(g_launches)).c_str()); Roctx::get().pop(); }
     return c.side_join();
 }
 

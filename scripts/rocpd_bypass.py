@@ -37,23 +37,45 @@ for t in tables:
 if not marks:
     print("no roctx ranges found; tables:", tables)
     sys.exit(0)
-# host ranges and device kernels live on different clocks in general; rocprofv3 reports both in the same (system) domain, and a kernel
-# cannot START before it was enqueued: attribute a kernel to the range whose host interval contains its enqueue ... which the kernel trace
-# does not record.  Approximation that is exact for a serialised stream: kernels in start order are consumed range by range, each range
-# taking the kernels that start before the NEXT range's first kernel; the split point is found by matching counts through the gaps between
-# ranges (every launch happens inside some range except the few glue kernels between passes, which are reported as "(between passes)").
+# Kernels are asynchronous: a range's host interval says nothing about when its kernels ran.  Every range label carries the library's launch
+# counter at its opening ("name#k@N"), a "~end@N" marker follows its close: the range owns the library launches [N_open, N_end) in LAUNCH
+# ORDER = start order of the library's kernels on a single stream (trace with ACLGAN_SIDE_STREAM=0).  torch's own kernels and runtime fills
+# are not counted by the library and are left out on both sides.
+import re
+lib = [k for k in kern if "at::native" not in str(k[0]) and "rocclr" not in str(k[0])]
 marks.sort(key=lambda r: r[1])
-out = defaultdict(lambda: [0, 0.0])
-ki = 0
-for i, (label, s, e) in enumerate(marks):
-    nxt = marks[i + 1][1] if i + 1 < len(marks) else None
-    # kernels that started before this range opened on the host belong to what came before
-    while ki < len(kern) and kern[ki][1] < s:
-        out["(between passes)"][0] += 1; out["(between passes)"][1] += kern[ki][2] - kern[ki][1]; ki += 1
-    while ki < len(kern) and (nxt is None or kern[ki][1] < nxt):
-        out[str(label)][0] += 1; out[str(label)][1] += kern[ki][2] - kern[ki][1]; ki += 1
+out = defaultdict(lambda: [0, 0.0, 0])
+allm = []
+for t in tables:
+    c = cols(t)
+    if "start" in c and "end" in c and t != kt:
+        ncol = [x for x in c if x in ("name", "message", "region_name", "label")] or [x for x in c if "name" in x]
+        if ncol:
+            try:
+                allm += [r for r in cur.execute("select %s, start, end from '%s'" % (ncol[0], t)).fetchall() if r[0] and "@" in str(r[0])]
+            except Exception:
+                pass
+allm = sorted(set(allm), key=lambda r: r[1])
+covered = 0
+for i, (label, s0, e0) in enumerate(allm):
+    label = str(label)
+    if label.startswith("~end"):
+        continue
+    m = re.match(r"(.*)@(\d+)$", label)
+    if not m or i + 1 >= len(allm):
+        continue
+    n0 = int(m.group(2))
+    m2 = re.match(r"~end@(\d+)$", str(allm[i + 1][0]))
+    if not m2:
+        continue
+    n1 = int(m2.group(1))
+    base = re.sub(r"#\d+$", lambda mm: mm.group(0), m.group(1))
+    t = sum(k[2] - k[1] for k in lib[n0:n1])
+    out[base][0] += n1 - n0; out[base][1] += t; out[base][2] += 1
+    covered += n1 - n0
+rest = len(lib) - covered
 tot = sum(v[1] for v in out.values())
-print("%-34s %8s %12s %7s" % ("range", "kernels", "kernel_us", "pct"))
-for k, (n, t) in sorted(out.items(), key=lambda kv: -kv[1][1]):
-    print("%-34s %8d %12.1f %7.2f" % (k[:34], n, t / 1e3, 100.0 * t / max(tot, 1)))
-print("%-34s %8d %12.1f" % ("TOTAL", sum(v[0] for v in out.values()), tot / 1e3))
+print("%-34s %6s %9s %12s %7s   (%d library kernels in the trace, %d outside any range)" % ("range", "times", "kernels", "kernel_us", "pct", len(lib), rest))
+for k, (n, t, occ) in sorted(out.items(), key=lambda kv: -kv[1][1]):
+    print("%-34s %6d %9d %12.1f %7.2f" % (k[:34], occ, n, t / 1e3, 100.0 * t / max(tot, 1)))
+print("%-34s %6s %9d %12.1f" % ("TOTAL (inside ranges)", "", sum(v[0] for v in out.values()), tot / 1e3))
