@@ -144,9 +144,9 @@ int set_glds_tile(int v);
 int set_dgrad16s_direct(int v);
 int set_wino_x3(int v);
 // conv_wino_fused.hip (round 4): Winograd F(4x4,3x3) as ONE launch -- input transform, 36 frequency GEMMs, output transform
-int wino_fused_mode();                           // 0 off, 1 fused
+int wino_fused_mode();                           // 0 off, 1 fused where the cost model says it pays, 2 fused wherever eligible
 int set_wino_fused(int v);                       // returns the previous mode
-bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act = ACLGAN_ACT_NONE);
+bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act = ACLGAN_ACT_NONE, int gph = 1, int kph = 1);
 int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st, int nph = 1);
 int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* Uf, const float* bias, float* out, int act, int accumulate,
                       int reflect, float2* stats, hipStream_t st);

@@ -679,7 +679,7 @@ size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g) {
 size_t conv_up5_wino_keep_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     if (wino_x3() && gemm_x3_shape_ok(1, g.Ci, g.Co)) return 0;
-    if (wino_fused_ok(g.B, g.Hi, g.Wi, g.Ci, g.Co, g.act)) return 0;      // the fused forward never materialises V
+    if (wino_fused_ok(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, g.act, 4, 1)) return 0;      // the fused forward never materialises V
     return align256((size_t)36 * up5_geo(g).T * g.Ci * sizeof(float));
 }
 int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV,
@@ -687,7 +687,7 @@ int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp,
     if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
-    if (!keepV && wino_fused_ok(g.B, g.Hi, g.Wi, g.Ci, g.Co, g.act)) {      // the four phases in one fused launch (conv_wino_fused.hip)
+    if (!keepV && wino_fused_ok(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, g.act, 4, 1)) {      // the four phases in one fused launch (conv_wino_fused.hip)
         bool fresh_f = true;
         float* Uf = cached_u((float*)scratch, wkey, 2, (size_t)144 * g.Co * g.Ci * 4, &fresh_f);
         if (fresh_f) { const int rcf = wino_fused_filter(wp, Uf, g.Co, g.Ci, 0, st, 4); if (rcf) return rcf; }
@@ -723,7 +723,7 @@ int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* 
     if (!conv_up5_wino_ok(g) || !scratch) return ACLGAN_EUNSUPPORTED;
     const Up5Geo q = up5_geo(g);
     char* cur = (char*)scratch;
-    if (wino_fused_ok(g.B, g.Hi, g.Wi, g.Co, g.Ci, ACLGAN_ACT_NONE)) {      // one fused launch: K loop over (phase, cout)
+    if (wino_fused_ok(g.B, g.Hi, g.Wi, g.Co, g.Ci, ACLGAN_ACT_NONE, 1, 4)) {      // one fused launch: K loop over (phase, cout)
         bool fresh_f = true;
         float* Uf = cached_u((float*)scratch, wkey, 3, (size_t)144 * g.Co * g.Ci * 4, &fresh_f);
         if (fresh_f) { const int rcf = wino_fused_filter(wp, Uf, g.Co, g.Ci, 1, st, 4); if (rcf) return rcf; }

@@ -26,6 +26,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <algorithm>
+#include <cmath>
 
 namespace aclgan {
 
@@ -428,21 +429,35 @@ int g_wino_fused = -1;
 
 }  // namespace
 
-// tuning / test knob behind aclgan_set_tuning("wino_fused", v): 0 = the three-launch pipeline of conv_wino.hip, 1 = the fused kernel;
+// tuning / test knob behind aclgan_set_tuning("wino_fused", v): 0 = the three-launch pipeline of conv_wino.hip, 1 = the fused kernel where its
+// cost model says it pays (wino_fused_ok), 2 = the fused kernel wherever the shape is eligible;
 // returns the previous value.  ACLGAN_WINO_FUSED sets the default.  (bits 4.. select a measurement build when compiled with
 // -DACLGAN_FUSED_ABLATION)
 int wino_fused_mode() {
-    if (g_wino_fused < 0) { const char* e = getenv("ACLGAN_WINO_FUSED"); g_wino_fused = e ? atoi(e) : 1; if (g_wino_fused < 0 || (g_wino_fused & 15) > 1) g_wino_fused = 1; }
+    if (g_wino_fused < 0) { const char* e = getenv("ACLGAN_WINO_FUSED"); g_wino_fused = e ? atoi(e) : 1; if (g_wino_fused < 0 || (g_wino_fused & 15) > 2) g_wino_fused = 1; }
     return g_wino_fused;
 }
-int set_wino_fused(int v) { const int old = wino_fused_mode(); g_wino_fused = (v < 0 || (v & 15) > 1) ? 1 : v; return old; }
+int set_wino_fused(int v) { const int old = wino_fused_mode(); g_wino_fused = (v < 0 || (v & 15) > 2) ? 1 : v; return old; }
 
-// the fused kernel takes: K-side channels a multiple of 16, output channels a multiple of 64, byte offsets below 2^31; no tanh epilogue
-bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act) {
+// the fused kernel takes: K-side channels a multiple of 16, output channels a multiple of 64, byte offsets below 2^31; no tanh epilogue.
+// Mode 1 (default) additionally asks the cost model below whether the one-launch kernel PAYS for this grid; mode 2 takes it whenever the
+// shape is eligible (tests).  gph: grid phases (forward of the sub-pixel layers: 4 launch-parallel phases), kph: K phases (their input gradient).
+//
+// Cost model (microseconds, measured on the ResBlock channel counts, scripts/probe_fused_abl.py B = 1 .. 8, round 4): a workgroup of the fused
+// kernel walks the whole K loop whatever the grid size -- 10 + 83 * K / 256 us per round of 256 workgroups -- while the three-launch pipeline
+// scales with the tile count: 30 + 0.0488 us per (tile x 256 x 256 channel pair).  Crossover on the 256-channel ResBlock: ~1400 tiles (B = 5.5 at
+// 64 x 64); below it (the reference's own batch_size 3, the 64 x 64 B = 1 launch-floor probe) the pipeline is faster (B = 1: 42 against 93 us).
+bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act, int gph, int kph) {
     const int m = wino_fused_mode() & 15;
     if (m == 0) return false;
-    return act != ACLGAN_ACT_TANH && Cin_ % (2 * KC) == 0 && Cout_ % NBC == 0 && (long long)4 * 36 * Cin_ * Cout_ * 4 < 0x7fffffe0ll && H >= 4 && W >= 4 &&
-           (long long)B * (2 * H + 8) * (2 * W + 8) * std::max(Cin_, Cout_) * 4 < 0x7fffffe0ll;
+    const bool shape = act != ACLGAN_ACT_TANH && Cin_ % (2 * KC) == 0 && Cout_ % NBC == 0 && (long long)4 * 36 * Cin_ * Cout_ * 4 < 0x7fffffe0ll && H >= 4 && W >= 4 &&
+                       (long long)B * (2 * H + 8) * (2 * W + 8) * std::max(Cin_, Cout_) * 4 < 0x7fffffe0ll;
+    if (!shape || m == 2) return shape;
+    const int TY = cdiv(H, 4), TX = cdiv(W, 4);
+    const double nwg = (double)B * cdiv(TY, TBY) * cdiv(TX, TBX) * (Cout_ / NBC) * gph;
+    const double t_fused = (10.0 + 83.0 * (double)Cin_ * kph / 256.0) * std::ceil(nwg / 256.0);
+    const double t_pipe = 30.0 + 0.0488 * (double)B * TY * TX * gph * kph * ((double)Cin_ * Cout_ / 65536.0);
+    return t_fused <= t_pipe;
 }
 size_t wino_fused_u_bytes(int Cin_, int Cout_) { return (size_t)36 * Cin_ * Cout_ * sizeof(float); }
 
@@ -498,7 +513,7 @@ int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in,
 // x[B][Hi][Wi][Cin_].  Uf: the four merged phase filters in fragment order, back to back.  One launch, blockIdx.y = phase.
 int wino_fused_up5_fwd(int B, int Hi, int Wi, int Cin_, int Cout_, const float* x, const float* Uf, const float* bias, float* y, int Hf, int Wf, int act,
                        hipStream_t st) {
-    if (!wino_fused_ok(B, Hi, Wi, Cin_, Cout_, act) || Hi < 6 || Wi < 6) return ACLGAN_EUNSUPPORTED;
+    if (!wino_fused_ok(B, Hi - 2, Wi - 2, Cin_, Cout_, act, 4, 1) || Hi < 6 || Wi < 6) return ACLGAN_EUNSUPPORTED;
     WfP p;
     p.x = x; p.Uf = Uf; p.bias = bias; p.y = y; p.stats = nullptr;
     p.B = B; p.Cin = Cin_; p.Cout = Cout_;
@@ -512,7 +527,7 @@ int wino_fused_up5_fwd(int B, int Hi, int Wi, int Cin_, int Cout_, const float* 
 // ... and their input gradient: dx[B][Hi][Wi][Cin_] (+)= sum over the phases of the full correlation of the phase view of dy[B][Hf][Wf][Cout_]
 // with the flipped merged filter: ONE K loop over (phase, cout), the sum over the phases happens in the accumulators.
 int wino_fused_up5_dgrad(int B, int Hi, int Wi, int Cin_, int Cout_, const float* dy, const float* Uf, float* dx, int Hf, int Wf, int accumulate, hipStream_t st) {
-    if (!wino_fused_ok(B, Hi, Wi, Cout_, Cin_, ACLGAN_ACT_NONE) || Hi < 6 || Wi < 6) return ACLGAN_EUNSUPPORTED;
+    if (!wino_fused_ok(B, Hi, Wi, Cout_, Cin_, ACLGAN_ACT_NONE, 1, 4) || Hi < 6 || Wi < 6) return ACLGAN_EUNSUPPORTED;
     WfP p;
     p.x = dy; p.Uf = Uf; p.bias = nullptr; p.y = dx; p.stats = nullptr;
     p.B = B; p.Cin = Cout_; p.Cout = Cin_;

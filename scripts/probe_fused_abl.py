@@ -3,7 +3,7 @@ import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import aclgan_amd  # noqa
 from aclgan_amd import _lib as L
-B, Hi, Cc = 8, 64, 256
+B, Hi, Cc = int(os.environ.get("B", "8")), int(os.environ.get("HI", "64")), 256
 x = torch.randn(B, Hi, Hi, Cc, device="cuda"); w = torch.randn(Cc, 3, 3, Cc, device="cuda") * 0.02
 b = torch.zeros(Cc, device="cuda"); y = torch.empty(B, Hi, Hi, Cc, device="cuda")
 d = L.ConvDesc(B, Hi, Hi, Cc, Cc, 3, 1, 1, 0, 0)

@@ -18,24 +18,18 @@ kt = "kernels" if "kernels" in tables else [t for t in tables if "kernel" in t.l
 kc = cols(kt)
 name_col = "name" if "name" in kc else [c for c in kc if "name" in c][0]
 kern = cur.execute("select %s, start, end from %s order by start" % (name_col, kt)).fetchall()
-# marker / region table: anything with start, end and a name-like column that holds our labels
+import json
 marks = []
-for t in tables:
-    c = cols(t)
-    if "start" in c and "end" in c and t != kt:
-        ncol = [x for x in c if x in ("name", "message", "region_name", "label")] or [x for x in c if "name" in x]
-        if not ncol:
-            continue
+if "regions" in tables:
+    for ext, st, en in cur.execute("select extdata, start, end from regions order by start").fetchall():
         try:
-            rows = cur.execute("select %s, start, end from '%s'" % (ncol[0], t)).fetchall()
+            msg = json.loads(ext).get("message")
         except Exception:
-            continue
-        rows = [r for r in rows if r[0] and any(str(r[0]).startswith(p) for p in ("gen_", "dis_", "bwd:"))]
-        if rows:
-            marks = rows
-            break
+            msg = None
+        if msg and "@" in msg:
+            marks.append((msg, st, en))
 if not marks:
-    print("no roctx ranges found; tables:", tables)
+    print("no roctx ranges found (run with ACLGAN_ROCTX=1 and --marker-trace); tables:", [t for t in tables if "_0000" not in t])
     sys.exit(0)
 # Kernels are asynchronous: a range's host interval says nothing about when its kernels ran.  Every range label carries the library's launch
 # counter at its opening ("name#k@N"), a "~end@N" marker follows its close: the range owns the library launches [N_open, N_end) in LAUNCH
@@ -43,19 +37,8 @@ if not marks:
 # are not counted by the library and are left out on both sides.
 import re
 lib = [k for k in kern if "at::native" not in str(k[0]) and "rocclr" not in str(k[0])]
-marks.sort(key=lambda r: r[1])
 out = defaultdict(lambda: [0, 0.0, 0])
-allm = []
-for t in tables:
-    c = cols(t)
-    if "start" in c and "end" in c and t != kt:
-        ncol = [x for x in c if x in ("name", "message", "region_name", "label")] or [x for x in c if "name" in x]
-        if ncol:
-            try:
-                allm += [r for r in cur.execute("select %s, start, end from '%s'" % (ncol[0], t)).fetchall() if r[0] and "@" in str(r[0])]
-            except Exception:
-                pass
-allm = sorted(set(allm), key=lambda r: r[1])
+allm = sorted(set(marks), key=lambda r: r[1])
 covered = 0
 for i, (label, s0, e0) in enumerate(allm):
     label = str(label)

@@ -117,6 +117,45 @@ def test_winograd_with_split_bf16_gemm_slices(L, case):
     assert e1 <= 1.5 * e0 + 1e-6, (e0, e1)
 
 
+@pytest.mark.parametrize("case", WINO_X3_CASES + [(2, 64, 64, 128, 128, 3, 1, 1, 0, "none"), (1, 16, 16, 128, 64, 5, 1, 2, 1, "none")])
+def test_winograd_fused_kernel(L, case):
+    """csrc/conv_wino_fused.hip (round 4): Winograd F(4x4,3x3) with the input transform, the 36 frequency GEMMs and the output transform in
+    ONE launch -- the ResBlock convolutions and the four sub-pixel phases of the upsample + 5x5 layers, forward and input gradient.  The step
+    takes it where its cost model says it pays (large grids); here it is FORCED (tuning mode 2) on every eligible shape, small and ragged
+    ones included, and must agree with the oracle like the three-launch pipeline (mode 0) does, accumulate mode included."""
+    from gpu_util import conv_desc, gpu_conv_fwd, gpu_conv_dgrad, nhwc, nchw, ohwi, rel_err
+    B, Hi, Wi, Ci, Co, k, s, p, up, act = case
+    x, w, b = _case_tensors(case, 7)
+    x.requires_grad_(True)
+    ref = O.conv_block(x, w, b, s, p, act, upsample=bool(up))
+    y_lin = O.conv_block(x, w, b, s, p, "none", upsample=bool(up))
+    dy = torch.randn(y_lin.shape, generator=torch.Generator().manual_seed(5))
+    y_lin.backward(dy)
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, act)
+    dn = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, "none")
+    xg, wg, bg, dyg = nhwc(x.detach()).cuda(), ohwi(w).cuda(), b.cuda(), nhwc(dy).cuda()
+    base = torch.randn(B, Hi, Wi, Ci, generator=torch.Generator().manual_seed(6))
+    out = {}
+    old = L.lib.aclgan_set_tuning(b"wino_fused", 0)
+    try:
+        for v in (0, 2):
+            L.lib.aclgan_set_tuning(b"wino_fused", v)
+            n0 = L.lib.aclgan_launch_count()
+            y = gpu_conv_fwd(L, d, xg, wg, bg)
+            launches = L.lib.aclgan_launch_count() - n0
+            out[v] = (y, gpu_conv_dgrad(L, dn, dyg, wg), gpu_conv_dgrad(L, dn, dyg, wg, accumulate_into=base.clone().cuda()), launches)
+    finally:
+        L.lib.aclgan_set_tuning(b"wino_fused", old)
+    for v in (0, 2):
+        assert rel_err(nchw(out[v][0]), ref) < TOL
+        assert rel_err(nchw(out[v][1]), x.grad) < TOL
+        assert rel_err(nchw(out[v][2]).cpu() - nchw(base), x.grad) < 5 * TOL
+    if Co % 64 == 0 and Ci % 16 == 0:
+        assert out[2][3] < out[0][3], "the forced mode did not take the fused kernel (launch counts %d vs %d)" % (out[2][3], out[0][3])
+    # same arithmetic, different summation order
+    assert rel_err(out[2][0], out[0][0]) < 5e-5 and rel_err(out[2][1], out[0][1]) < 5e-5
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(L, case):
     from gpu_util import conv_desc, gpu_conv_dgrad, nhwc, nchw, ohwi, rel_err
@@ -302,8 +341,17 @@ BLOCK_CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 2], ids=["three-launch", "one-launch"])
+def wino_mode(L, request):
+    """the Winograd layers through the three-launch pipeline (tuning mode 0) and through the fused kernel on every eligible shape (mode 2);
+    the default (mode 1) picks between them by grid size"""
+    old = L.lib.aclgan_set_tuning(b"wino_fused", request.param)
+    yield request.param
+    L.lib.aclgan_set_tuning(b"wino_fused", old)
+
+
 @pytest.mark.parametrize("case", BLOCK_CASES)
-def test_conv_block_fwd(L, case):
+def test_conv_block_fwd(L, case, wino_mode):
     from gpu_util import conv_desc, nhwc, nchw, ohwi, rel_err
     B, H, W, Ci, Co, k, kind, act, use_res, expect_fused = case
     s, p = (2, 1) if k == 4 else (1, 1)
