@@ -209,7 +209,14 @@ struct aclgan_ctx {
     int side_fork() {       // the side stream may start once everything enqueued on the main stream so far is done
         if (dry) return ACLGAN_OK;
         if (!st2) {
-            hipError_t e = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
+            // ACLGAN_SIDE_PRIO=1: the side stream at the highest priority the device offers (its kernels are small and fill the tails of the
+            // main stream's launches; measured in round 4, see profiles/r04_experiments.md)
+            static int prio = -1;
+            if (prio < 0) { const char* pe = getenv("ACLGAN_SIDE_PRIO"); prio = pe ? atoi(pe) : 0; }
+            int lo = 0, hi = 0;
+            hipError_t e = hipSuccess;
+            if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) e = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, prio > 0 ? hi : lo);
+            else e = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
             if (e != hipSuccess) return aclgan::hip_fail(e, "side stream");
