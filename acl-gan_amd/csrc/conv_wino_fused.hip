@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace aclgan {
 
@@ -136,6 +137,12 @@ __device__ __forceinline__ f32x2 opaque2(float v) {      // a constant pair the 
     return r;
 }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 opaque4(float v) {
+    f32x4 r = {v, v, v, v};
+    asm volatile("" : "+v"(r));
+    return r;
+}
 struct BtK { f32x2 k4, k5n, k4n, k2, k2n; };
 // three rows of B^T d: W = 0: rows 0, 1, 2 from d0..d4;  W = 1: rows 3, 4, 5 from d1..d5  (x = the five inputs that set needs): 6 packed operations
 template <int W>
@@ -355,6 +362,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int n = cb * NBC + c4 * 4;
     const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4)(0.f);
     const float slope = p.act == ACLGAN_ACT_RELU ? 0.f : (p.act == ACLGAN_ACT_LRELU ? 0.2f : 1.f);      // act(v) = max(v, 0) + slope * min(v, 0)
+    const f32x4 k2 = opaque4(2.f), k4 = opaque4(4.f), k8 = opaque4(8.f);
 #pragma unroll
     for (int P = 0; P < ((ABL & 512) ? 0 : 2); ++P) {
         __syncthreads();                          // the patch buffers / the previous half are no longer read
@@ -377,51 +385,65 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int rows = live ? min(4, p.OH - 4 * ty) : 0, cols = live ? min(4, p.OW - 4 * tx) : 0;      // ragged last tiles of a view
         float* ybase = p.y + (((size_t)b * p.OHS + ovy0 + p.ovs * 4 * (live ? ty : 0)) * p.OWS + ovx0 + p.ovs * 4 * (live ? tx : 0)) * p.Cout + n;
         const size_t yrs = (size_t)p.ovs * p.OWS * p.Cout, ycs = (size_t)p.ovs * p.Cout;
-        f32x4 old[4][4];
-        if (p.accumulate) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) old[a][bb] = (a < rows && bb < cols) ? *reinterpret_cast<const f32x4*>(ybase + a * yrs + bb * ycs) : (f32x4)(0.f);
-        }
+        // A^T m along one axis, factored: 10 vector operations (y0 = m0 + s12 + s34, y1 = d12 + 2 d34, y2 = s12 + 4 s34, y3 = d12 + 8 d34 + m5)
+        auto at4v = [&](const f32x4 (&m)[6], f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) __attribute__((always_inline)) {
+            const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            y0 = m[0] + s12 + s34;
+            y1 = fma4(k2, d34, d12);
+            y2 = fma4(k4, s34, s12);
+            y3 = fma4(k8, d34, d12) + m[5];
+        };
         f32x4 tmp[4][6];
 #pragma unroll
         for (int jf = 0; jf < 6; ++jf) {
             f32x4 m[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(Ms + ((i * 6 + jf) * 16 + tl) * 64 + c4 * 4);
-            tmp[0][jf] = m[0] + m[1] + m[2] + m[3] + m[4];
-            tmp[1][jf] = m[1] - m[2] + 2.f * (m[3] - m[4]);
-            tmp[2][jf] = m[1] + m[2] + 4.f * (m[3] + m[4]);
-            tmp[3][jf] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
+            at4v(m, tmp[0][jf], tmp[1][jf], tmp[2][jf], tmp[3][jf]);
         }
-        f32x4 sh = (f32x4)(0.f), s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
+        // the store loop in the variants the step uses (every fused convolution of the step has act none: a normalisation layer or nothing follows):
+        // plain store + tile statistics (forward), plain store (sub-pixel phases), accumulate (input gradients); everything else: generic
+        auto finish = [&](auto ACT_, auto ACC_, auto STATS_) __attribute__((always_inline)) {
+            constexpr bool ACT = decltype(ACT_)::value, ACC = decltype(ACC_)::value, STATS = decltype(STATS_)::value;
+            f32x4 sh = (f32x4)(0.f), s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const f32x4 (&q)[6] = tmp[a];
-            f32x4 o[4];
-            o[0] = q[0] + q[1] + q[2] + q[3] + q[4];
-            o[1] = q[1] - q[2] + 2.f * (q[3] - q[4]);
-            o[2] = q[1] + q[2] + 4.f * (q[3] + q[4]);
-            o[3] = q[1] - q[2] + 8.f * (q[3] - q[4]) + q[5];
+            for (int a = 0; a < 4; ++a) {
+                f32x4 o[4], old[4];
+                if (ACC) {
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                f32x4 v = o[bb] + bv, val;
+                    for (int bb = 0; bb < 4; ++bb) old[bb] = (a < rows && bb < cols) ? *reinterpret_cast<const f32x4*>(ybase + a * yrs + bb * ycs) : (f32x4)(0.f);
+                }
+                at4v(tmp[a], o[0], o[1], o[2], o[3]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = fmaxf(v[e], 0.f) + slope * fminf(v[e], 0.f);
-                if (p.accumulate) val += old[a][bb];
-                if (a < rows && bb < cols && !(ABL & 128)) *reinterpret_cast<f32x4*>(ybase + a * yrs + bb * ycs) = val;
-                if (a == 0 && bb == 0) sh = val;
-                const f32x4 dv = val - sh;
-                s1 += dv; s2 += dv * dv;
+                for (int bb = 0; bb < 4; ++bb) {
+                    f32x4 val = o[bb] + bv;
+                    if (ACT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f) + slope * fminf(val[e], 0.f);
+                    }
+                    if (ACC) val += old[bb];
+                    if (a < rows && bb < cols && !(ABL & 128)) *reinterpret_cast<f32x4*>(ybase + a * yrs + bb * ycs) = val;
+                    if (STATS) {
+                        if (a == 0 && bb == 0) sh = val;
+                        const f32x4 dv = val - sh;
+                        s1 += dv; s2 += dv * dv;
+                    }
+                }
             }
-        }
-        if (p.stats && live) {      // (mean, M2) of the tile's 16 outputs per channel: the chunk partials norm_finalize_* combines
-            const f32x4 mean = sh + s1 * (1.f / 16.f), m2 = s2 - s1 * s1 * (1.f / 16.f);
-            float* so = reinterpret_cast<float*>(p.stats + (((size_t)b * p.TY + ty) * p.TX + tx) * p.Cout + n);
-            *reinterpret_cast<f32x4*>(so) = (f32x4){mean[0], m2[0], mean[1], m2[1]};
-            *reinterpret_cast<f32x4*>(so + 4) = (f32x4){mean[2], m2[2], mean[3], m2[3]};
-        }
+            if (STATS && live) {      // (mean, M2) of the tile's 16 outputs per channel: the chunk partials norm_finalize_* combines
+                const f32x4 mean = sh + s1 * (1.f / 16.f), m2 = s2 - s1 * s1 * (1.f / 16.f);
+                float* so = reinterpret_cast<float*>(p.stats + (((size_t)b * p.TY + ty) * p.TX + tx) * p.Cout + n);
+                *reinterpret_cast<f32x4*>(so) = (f32x4){mean[0], m2[0], mean[1], m2[1]};
+                *reinterpret_cast<f32x4*>(so + 4) = (f32x4){mean[2], m2[2], mean[3], m2[3]};
+            }
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
+        const bool actq = p.act != ACLGAN_ACT_NONE, accq = p.accumulate != 0, stq = p.stats != nullptr;
+        if (!actq && !accq && stq) finish(F_{}, F_{}, T_{});
+        else if (!actq && !accq && !stq) finish(F_{}, F_{}, F_{});
+        else if (!actq && accq && !stq) finish(F_{}, T_{}, F_{});
+        else if (accq) { if (stq) finish(T_{}, T_{}, T_{}); else finish(T_{}, T_{}, F_{}); }
+        else { if (stq) finish(T_{}, F_{}, T_{}); else finish(T_{}, F_{}, F_{}); }
     }
 }
 
