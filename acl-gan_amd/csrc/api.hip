@@ -76,7 +76,8 @@ int aclgan_winograd_filter_frag(const float* w, float* Uf, int Co, int Ci, int f
 int aclgan_conv3x3_winograd_fused(const float* x, const float* Uf, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int act, int reflect,
                                   int accumulate, float* stats, void* stream) {
     ACL_REQUIRE(x && Uf && y && B > 0, "conv3x3_winograd_fused: null argument");
-    const int old = set_wino_fused(2);      // (the entry point IS the fused kernel, whatever the step's switch and cost model say)
+    const int old = wino_fused_mode();
+    set_wino_fused((old & ~15) | 2);      // (the entry point IS the fused kernel, whatever the step's switch and cost model say)
     const int rc = wino_fused_launch(B, H, W, Cin, Cout, x, Uf, bias, y, act, accumulate, reflect, (float2*)stats, (hipStream_t)stream);
     set_wino_fused(old);
     if (rc == ACLGAN_EUNSUPPORTED) set_error("conv3x3_winograd_fused: shape not eligible (H, W multiples of 4, Cin of 16, Cout of 64, no tanh)");

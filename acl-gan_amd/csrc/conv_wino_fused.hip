@@ -89,7 +89,7 @@ __device__ __forceinline__ void g6f(const float (&g)[3], float (&u)[6]) {
     u[5] = g[2];
 }
 
-// U in fragment order: Uf[cb][kq][wave g][fi][j][lane][e]  (floats)
+// U in fragment order: Uf[cb][kq][wave g][fi][lane][j][e]  (floats): a lane's two 32-channel halves j of one frequency are ONE 16-byte load
 //   row R (forward: cout, dgrad: cin) = cb * 64 + j * 32 + (lane & 31);  k (forward: cin, dgrad: cout) = kq * 4 + 2 * (lane >> 5) + e
 //   frequency (i, jf): wave g = (i / 3) * 2 + jf / 3, fi = (i % 3) * 3 + jf % 3
 __global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __restrict__ w, float* __restrict__ Uf, int Co, int Ci, int flip) {
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __re
         }
         const int cb = row >> 6, j = (row >> 5) & 1, l31 = row & 31;
         const int kq = kk >> 2, h = (kk >> 1) & 1, e = kk & 1;
-        float* base = Uf + ((size_t)cb * KQ + kq) * (4 * 9 * 2 * 128) + (size_t)j * 128 + (h * 32 + l31) * 2 + e;
+        float* base = Uf + ((size_t)cb * KQ + kq) * (4 * 9 * 2 * 128) + (size_t)(h * 32 + l31) * 4 + j * 2 + e;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             float o[6];
@@ -180,38 +180,44 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
     const int lanebase = (h * QS + 4 * (l31 >> 3) * RS + (l31 & 7)) * 8;      // bytes
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Uf), 0, (int)p.ubytes, 0x00020000);
-    const int uvo = lane * 8;                                                  // lane part of a U fragment address
+    const int uvo = lane * 16;                                                 // lane part of a U fragment address (16 bytes: both 32-channel halves)
     const int ustep = 4 * 9 * 2 * 64 * 8;                                      // bytes of one 4-channel step of a channel block
     const int ubase = (cb * KQp * 4 + wave) * (9 * 2 * 64 * 8) + (int)blockIdx.y * p.uphase;      // (blockIdx.y: grid phase)
-    auto kphase = [&](int c) __attribute__((always_inline)) { return (c >= nchp) + (c >= 2 * nchp) + (c >= 3 * nchp); };      // scalar
+    // SCALAR byte offsets of a chunk of x (channel offset inside its K phase + the phase view's offset) and of a 4-channel step of U, computed
+    // once per sub-step on the scalar unit and pinned to an SGPR.  (Round 4: written as arithmetic on comparison results, the compiler moved
+    // them to the VALU and wrapped every buffer load in a readfirstlane waterfall loop -- 12 us per launch.)
+    auto xoff = [&](int chunk) __attribute__((always_inline)) {
+        int c = min(chunk, nch - 1), xo = 0;
+        if (c >= nchp) { c -= nchp; xo = p.kph_xoff[1]; if (c >= nchp) { c -= nchp; xo = p.kph_xoff[2]; if (c >= nchp) { c -= nchp; xo = p.kph_xoff[3]; } } }
+        return __builtin_amdgcn_readfirstlane(c * (KC * 4) + xo);
+    };
+    auto uoff = [&](int kq) __attribute__((always_inline)) {
+        int q = min(kq, 2 * nch - 1), so = ubase;
+        if (q >= KQp) { q -= KQp; so += p.uphase; if (q >= KQp) { q -= KQp; so += p.uphase; if (q >= KQp) { q -= KQp; so += p.uphase; } } }
+        return __builtin_amdgcn_readfirstlane(so + q * ustep);
+    };
     const BtK bk = {opaque2(4.f), opaque2(-5.f), opaque2(-4.f), opaque2(2.f), opaque2(-2.f)};
 
     // ---- staging of the raw patch: piece i of a chunk is issued at window slice 3i and written to LDS at slice 3i + 5 ----
     f32x4 xr[2];
-    auto xissue = [&](int chunk, int i) __attribute__((always_inline)) {
-        const int c = min(chunk, nch - 1), ph = kphase(c);
-        const int xo = ph == 0 ? 0 : (ph == 1 ? p.kph_xoff[1] : (ph == 2 ? p.kph_xoff[2] : p.kph_xoff[3]));
-        xr[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], (c - ph * nchp) * KC * 4 + xo, 0));
+    auto xissue = [&](int xso, int i) __attribute__((always_inline)) {       // xso = xoff(chunk)
+        xr[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], xso, 0));
     };
     auto xwrite = [&](int par, int i) __attribute__((always_inline)) {       // par: parity of the chunk = its LDS buffer (compile time)
         char* dst = smem + par * XBUF * 8 + lub[i];
         *reinterpret_cast<f32x2*>(dst) = (f32x2){xr[i & 1].x, xr[i & 1].y};
         *reinterpret_cast<f32x2*>(dst + QS * 8) = (f32x2){xr[i & 1].z, xr[i & 1].w};
     };
-    auto xslot = [&](int chunk, int par, int wsl) __attribute__((always_inline)) {
+    auto xslot = [&](int xso, int par, int wsl) __attribute__((always_inline)) {
         if (wsl >= 5 && (wsl - 5) % 3 == 0 && (wsl - 5) / 3 < NP) xwrite(par, (wsl - 5) / 3);
-        if (wsl % 3 == 0 && wsl / 3 < NP) xissue(chunk, wsl / 3);
+        if (wsl % 3 == 0 && wsl / 3 < NP) xissue(xso, wsl / 3);
     };
 
     f32x2 u[9][2];
-    auto uload = [&](int kq, int fi) __attribute__((always_inline)) {
-        const int q = min(kq, 2 * nch - 1), ph = kphase(q >> 1);
-        const int so = ubase + ph * p.uphase + (q - ph * KQp) * ustep;           // scalar
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = fi * 2 + j;
-            u[fi][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ru, uvo + (idx & 7) * 512, so + (idx >> 3) * 4096, 0));
-        }
+    auto uload = [&](int so, int fi) __attribute__((always_inline)) {        // so = uoff(4-channel step)
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvo + (fi & 3) * 1024, so + (fi >> 2) * 4096, 0));
+        u[fi][0] = (f32x2){v.x, v.y};
+        u[fi][1] = (f32x2){v.z, v.w};
     };
     // the wave's 5 x 5 sub-patch of one sub-step (read from LDS well ahead of the burst that transforms it)
     f32x2 d[5][5];      // [column][row]
@@ -240,10 +246,11 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
         f32x4 xp[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], 0, 0));
-        xissue(1, 0);
-        xissue(1, 1);
+        const int xso1 = xoff(1);
+        xissue(xso1, 0);
+        xissue(xso1, 1);
 #pragma unroll
-        for (int fi = 0; fi < UD; ++fi) uload(0, fi);
+        for (int fi = 0; fi < UD; ++fi) uload(uoff(0), fi);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             *reinterpret_cast<f32x2*>(smem + lub[i]) = (f32x2){xp[i].x, xp[i].y};
@@ -251,7 +258,7 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
         }
         // = the state after window slices 0 .. 8 of chunk 1: pieces 0, 1 written, piece 2 in flight
         xwrite(1, 0);
-        xissue(1, 2);
+        xissue(xso1, 2);
         xwrite(1, 1);
     }
     __syncthreads();
@@ -272,15 +279,16 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
         // staging window of chunk ch + 1: sub-steps (ch - 1, 1), (ch, 0); the last sub-step already stages ch + 2 (into this chunk's buffer)
         const int schunk = ss == 1 ? ch + 2 : ch + 1, spar = ss == 1 ? par : par ^ 1;
         const int wbase = ss == 1 ? 0 : 9;
+        const int so_cur = uoff(kq), so_nxt = uoff(kq + 1), xso = xoff(schunk);
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             mfma1(s, 0, Vc[s].x, u[s][0].x);
             mfma1(s, 1, Vc[s].x, u[s][1].x);
             mfma1(s, 0, Vc[s].y, u[s][0].y);
             mfma1(s, 1, Vc[s].y, u[s][1].y);
-            if (!(ABL & 2)) uload(s + UD < 9 ? kq : kq + 1, (s + UD) % 9);
+            if (!(ABL & 2)) uload(s + UD < 9 ? so_cur : so_nxt, (s + UD) % 9);
             if (s < 5 && !(ABL & 1)) rdcol(npar, ns, s);
-            if (!(ABL & 4)) xslot(schunk, spar, wbase + s);
+            if (!(ABL & 4)) xslot(xso, spar, wbase + s);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!(ABL & 1)) transform(Vn);
