@@ -163,7 +163,7 @@ __device__ __forceinline__ void bt3(const BtK& k, const f32x2 (&x)[5], f32x2& o0
 constexpr int KC = 8;                            // input channels per staged chunk (two 4-channel MFMA sub-steps)
 constexpr int NP = 5;                            // 16-byte staging pieces per thread and chunk (612 pixels x 2 pieces <= 5 x 256)
 constexpr int XBUF = (KC / 2) * QS;              // 8-byte units per patch buffer
-constexpr int UD = 8;                            // U fragments are loaded UD slices ahead of their MFMAs
+constexpr int UD = 17;                           // U fragments are loaded UD slices (almost two sub-steps) ahead of their MFMAs: two register sets
 
 // One wave's share of the K loop.  WI, WJ: the wave's frequency block.
 // MEASURED (scripts/microbench/mfma_valu_overlap.hip): v_mfma_f32_32x32x2_f32 runs on the fp32 VALU lanes -- a VALU instruction of the same
@@ -198,26 +198,27 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
     };
     const BtK bk = {opaque2(4.f), opaque2(-5.f), opaque2(-4.f), opaque2(2.f), opaque2(-2.f)};
 
-    // ---- staging of the raw patch: piece i of a chunk is issued at window slice 3i and written to LDS at slice 3i + 5 ----
-    f32x4 xr[2];
+    // ---- staging of the raw patch: the NP pieces of a chunk are issued at window slices 0 .. NP-1 and written to LDS at slices 12 .. 12+NP-1 of
+    // the 18-slice window (12 slices = ~1.5 us in flight: an L2 miss to the Infinity Cache has landed; the main loop has the registers) ----
+    f32x4 xr[NP];
     auto xissue = [&](int xso, int i) __attribute__((always_inline)) {       // xso = xoff(chunk)
-        xr[i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], xso, 0));
+        xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], xso, 0));
     };
     auto xwrite = [&](int par, int i) __attribute__((always_inline)) {       // par: parity of the chunk = its LDS buffer (compile time)
         char* dst = smem + par * XBUF * 8 + lub[i];
-        *reinterpret_cast<f32x2*>(dst) = (f32x2){xr[i & 1].x, xr[i & 1].y};
-        *reinterpret_cast<f32x2*>(dst + QS * 8) = (f32x2){xr[i & 1].z, xr[i & 1].w};
+        *reinterpret_cast<f32x2*>(dst) = (f32x2){xr[i].x, xr[i].y};
+        *reinterpret_cast<f32x2*>(dst + QS * 8) = (f32x2){xr[i].z, xr[i].w};
     };
     auto xslot = [&](int xso, int par, int wsl) __attribute__((always_inline)) {
-        if (wsl >= 5 && (wsl - 5) % 3 == 0 && (wsl - 5) / 3 < NP) xwrite(par, (wsl - 5) / 3);
-        if (wsl % 3 == 0 && wsl / 3 < NP) xissue(xso, wsl / 3);
+        if (wsl >= 12 && wsl - 12 < NP) xwrite(par, wsl - 12);
+        if (wsl < NP) xissue(xso, wsl);
     };
 
-    f32x2 u[9][2];
-    auto uload = [&](int so, int fi) __attribute__((always_inline)) {        // so = uoff(4-channel step)
+    f32x2 u[2][9][2];      // [sub-step parity][frequency][32-channel half]
+    auto uload = [&](int so, int par2, int fi) __attribute__((always_inline)) {        // so = uoff(4-channel step), par2 = its parity
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvo + (fi & 3) * 1024, so + (fi >> 2) * 4096, 0));
-        u[fi][0] = (f32x2){v.x, v.y};
-        u[fi][1] = (f32x2){v.z, v.w};
+        u[par2][fi][0] = (f32x2){v.x, v.y};
+        u[par2][fi][1] = (f32x2){v.z, v.w};
     };
     // the wave's 5 x 5 sub-patch of one sub-step (read from LDS well ahead of the burst that transforms it)
     f32x2 d[5][5];      // [column][row]
@@ -246,20 +247,19 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
         f32x4 xp[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, go[i], 0, 0));
-        const int xso1 = xoff(1);
-        xissue(xso1, 0);
-        xissue(xso1, 1);
 #pragma unroll
-        for (int fi = 0; fi < UD; ++fi) uload(uoff(0), fi);
+        for (int fi = 0; fi < 9; ++fi) uload(uoff(0), 0, fi);
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi) uload(uoff(1), 1, fi);      // (fragment 8 of sub-step 1 is loaded by slice 0 of sub-step 0)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             *reinterpret_cast<f32x2*>(smem + lub[i]) = (f32x2){xp[i].x, xp[i].y};
             *reinterpret_cast<f32x2*>(smem + lub[i] + QS * 8) = (f32x2){xp[i].z, xp[i].w};
         }
-        // = the state after window slices 0 .. 8 of chunk 1: pieces 0, 1 written, piece 2 in flight
-        xwrite(1, 0);
-        xissue(xso1, 2);
-        xwrite(1, 1);
+        // = the state after window slices 0 .. 8 of chunk 1: every piece in flight
+        const int xso1 = xoff(1);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) xissue(xso1, i);
     }
     __syncthreads();
     f32x2 Va[9], Vb[9];
@@ -279,14 +279,15 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
         // staging window of chunk ch + 1: sub-steps (ch - 1, 1), (ch, 0); the last sub-step already stages ch + 2 (into this chunk's buffer)
         const int schunk = ss == 1 ? ch + 2 : ch + 1, spar = ss == 1 ? par : par ^ 1;
         const int wbase = ss == 1 ? 0 : 9;
-        const int so_cur = uoff(kq), so_nxt = uoff(kq + 1), xso = xoff(schunk);
+        const int so_nxt = uoff(kq + 1), so_nx2 = uoff(kq + 2), xso = xoff(schunk);
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            mfma1(s, 0, Vc[s].x, u[s][0].x);
-            mfma1(s, 1, Vc[s].x, u[s][1].x);
-            mfma1(s, 0, Vc[s].y, u[s][0].y);
-            mfma1(s, 1, Vc[s].y, u[s][1].y);
-            if (!(ABL & 2)) uload(s + UD < 9 ? so_cur : so_nxt, (s + UD) % 9);
+            mfma1(s, 0, Vc[s].x, u[ss][s][0].x);
+            mfma1(s, 1, Vc[s].x, u[ss][s][1].x);
+            mfma1(s, 0, Vc[s].y, u[ss][s][0].y);
+            mfma1(s, 1, Vc[s].y, u[ss][s][1].y);
+            // slice 0 fetches fragment 8 of the NEXT sub-step, slice s >= 1 fragment s - 1 of the one after (= this parity: just consumed)
+            if (!(ABL & 2)) uload(s == 0 ? so_nxt : so_nx2, s == 0 ? (ss ^ 1) : ss, (s + UD) % 9);
             if (s < 5 && !(ABL & 1)) rdcol(npar, ns, s);
             if (!(ABL & 4)) xslot(xso, spar, wbase + s);
             __builtin_amdgcn_sched_barrier(0);
