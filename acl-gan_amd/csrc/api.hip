@@ -251,6 +251,7 @@ int aclgan_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "glds_tile")) return set_glds_tile(value);
     if (key && !strcmp(key, "wino_x3")) return set_wino_x3(value);
     if (key && !strcmp(key, "wino_fused")) return set_wino_fused(value);
+    if (key && !strcmp(key, "wino_wgrad_fused")) return set_wino_wgrad_fused(value);
     if (key && !strcmp(key, "dgrad16s_direct")) return set_dgrad16s_direct(value);
     set_error("aclgan_set_tuning: unknown key");
     return -1;

@@ -152,6 +152,12 @@ int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in,
                       int reflect, float2* stats, hipStream_t st);
 int wino_fused_up5_fwd(int B, int Hi, int Wi, int Cin_, int Cout_, const float* x, const float* Uf, const float* bias, float* y, int Hf, int Wf, int act,
                        hipStream_t st);
+// conv_wino_wgrad_fused.hip (round 4): the Winograd weight / bias gradient of the 3x3 ResBlock layers as one kernel + one finish launch
+int wino_wgrad_fused_mode();                     // 0 off, 1 where the cost model says it pays, 2 wherever eligible
+int set_wino_wgrad_fused(int v);                 // returns the previous mode
+bool wino_wgrad_fused_ok(const ConvGeom& g);
+size_t wino_wgrad_fused_scratch_bytes(const ConvGeom& g);
+int wino_wgrad_fused(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
 int wino_fused_up5_dgrad(int B, int Hi, int Wi, int Cin_, int Cout_, const float* dy, const float* Uf, float* dx, int Hf, int Wf, int accumulate, hipStream_t st);
 // gemm_bf16x3.hip: fp32-accurate GEMM slices on the bf16 matrix cores from 3-plane (h, m, l) bf16 operands
 bool gemm_x3_shape_ok(int T, int K, int N);

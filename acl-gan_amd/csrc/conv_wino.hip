@@ -599,6 +599,7 @@ size_t conv_wino_keep_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     if (wino_x3() && gemm_x3_shape_ok(1, g.Ci, g.Co)) return 0;      // the forward writes V as bf16 planes; the fp32 weight-gradient GEMM transforms x itself
     if (wino_fused_ok(g.B, g.Hi, g.Wi, g.Ci, g.Co, g.act)) return 0;         // the fused forward never materialises V
+    if (wino_wgrad_fused_ok(g)) return 0;                                    // the fused weight gradient transforms x itself
     return align256((size_t)36 * g.B * (g.Ho / 4) * (g.Wo / 4) * g.Ci * sizeof(float));
 }
 int conv_fwd_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats, float* keepV) {
@@ -615,11 +616,14 @@ int conv_dgrad_wino_interior(const ConvGeom& g, const float* dy, const float* w,
 size_t conv_wgrad_wino_scratch_bytes(const ConvGeom& g) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0) return 0;
     const int64_t T = (int64_t)g.B * (g.Ho / 4) * (g.Wo / 4);
-    return align256((size_t)36 * T * g.Ci * 4) + align256((size_t)36 * T * g.Co * 4) + align256((size_t)36 * g.Co * g.Ci * 4) +
-           align256(WINO_BPART_BYTES + WINO_L2_BYTES) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
+    const size_t pipe = align256((size_t)36 * T * g.Ci * 4) + align256((size_t)36 * T * g.Co * 4) + align256((size_t)36 * g.Co * g.Ci * 4) +
+                        align256(WINO_BPART_BYTES + WINO_L2_BYTES) + gemm_at_b_slices_scratch((int)T, g.Co, g.Ci, 36) + 256;
+    // (sized for either path: the fused kernel is chosen per call -- the tuning switch may change between sizing and launch)
+    return std::max(pipe, wino_wgrad_fused_scratch_bytes(g));
 }
 int conv_wgrad_wino(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st, const float* haveV) {
     if (!conv_wino_ok(g) || g.Co % 64 != 0 || g.Ci % 64 != 0 || !scratch || !dw) return ACLGAN_EUNSUPPORTED;
+    if (wino_wgrad_fused_ok(g)) return wino_wgrad_fused(g, x, dy, dw, db, scratch, st);      // one kernel: neither V nor dM nor dU in memory
     if (!wino_bias_ok(g.Co)) return ACLGAN_EUNSUPPORTED;
     const int TY = g.Ho / 4, TX = g.Wo / 4;
     const int64_t T = (int64_t)g.B * TY * TX;

@@ -13,16 +13,16 @@
 //   A operand = dM: every lane reads the 4 x 4 block of dy of ITS tile pair and output channel from LDS and applies A . A^T restricted to the
 //               wave's 3 x 3 frequencies: 28 packed operations per 32-channel half.
 //   B operand = V: the 5 x 5 sub-patch of x of the tile pair and input channel, B^T . B restricted likewise: 48 packed operations.
-//   Raw dy / x strips are staged global -> registers -> LDS one group ahead (four LDS stages); all addresses are SGPR row offsets
+//   Raw dy / x strips are staged global -> registers -> LDS ahead (three LDS stages); all addresses are SGPR row offsets
 //   (computed per group on the scalar unit: batch, tile row, reflection) + one constant lane offset.
 //   epilogue = the 36 frequencies of a (co, ci) pair live in four waves: exchange through LDS (two passes of 144 KB), G^T dU G per thread,
 //              partial dw of this K slice stored as [slice][co][ky][kx][ci]; the bias gradient (column sums of dy) is accumulated from the
 //              staging registers by the workgroups of input-channel block 0.  wgrad_fused_finish_kernel adds the slices in order.
 //
 // LDS layout of a stage (bytes): x strip  [6 rows][22 pixel slots][32 ci] floats, slot(c) = c + (c >> 2)  (one empty slot after every 4 pixels);
-//                                dy strip [4 rows][16 pixels x 256 B + 128 B after every 4 pixels][64 co] floats.
-// The two lane halves (tiles h = 0 / 1, four pixels apart) are then 128 B (mod 256) apart: conflict-free; tiles h and h + 2 are a multiple of
-// 256 B apart: one ds_read2st64_b32 fetches the packed pair.
+//                                dy strip [2 co halves][4 rows][20 pixel slots][32 co] floats, the same slot rule.
+// A tile is 640 bytes wide in both: the two lane halves (tiles h = 0 / 1) are 128 B (mod 256) apart: conflict-free; tiles h and h + 2 are
+// 1280 B = 5 x 256 apart: one ds_read2st64_b32 fetches the packed pair; one lane base register serves both strips.
 #include "common.h"
 #include <cstdlib>
 #include <algorithm>
@@ -36,8 +36,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WCO = 64, WCI = 32;                // channels per workgroup
-constexpr int XROW = 22 * 128, XB = 6 * XROW;    // x strip: 16 896 bytes
-constexpr int DROW = 16 * 256 + 4 * 128, DB = 4 * DROW;      // dy strip: 18 432 bytes
+constexpr int XROW = 24 * 128, XB = 6 * XROW;    // x strip: rows of 3 x 1 KB copy chunks (22 slots used): 18 432 bytes
+constexpr int DROW = 20 * 128, DHALF = 4 * DROW, DB = 2 * DHALF;      // dy strip: two 32-channel halves of [4 rows][20 slots]: 20 480 bytes
 constexpr int STAGE = XB + DB;
 constexpr int NST = 4;
 constexpr int E_BYTES = 36 * 32 * 32 * 4;        // epilogue exchange buffer (one 32-output-channel half)
@@ -48,6 +48,10 @@ struct WgP {
     int B, H, W, Ci, Co, TY, TXS, G, ks, gper, nco, nci, want_db;
     long long xbytes, dybytes;
 };
+
+// the scalars the K loop needs, passed BY VALUE (a reference to the kernel-argument struct kept the whole struct in scratch memory here:
+// every field came back as a vector register and every buffer load was wrapped in a readfirstlane waterfall loop)
+struct WgS { const float* x; const float* dy; int xbytes, dybytes, H, W, Ci, Co, TY, TXS; };
 
 __device__ __forceinline__ int reflg(int v, int n) {
     v = v < 0 ? -v : v;
@@ -92,96 +96,153 @@ __device__ __forceinline__ void a3g(const TfK& k, const f32x2 (&y)[4], f32x2& o0
     }
 }
 
+// LDS reads of the K loop are written as ds_read2st64_b32 by hand: left to the compiler, the two halves of a packed pair were combined with
+// OTHER reads (ds_read2_b32 across pairs) and reassembled with ~80 v_mov per group, and addresses beyond the 16-bit offset field cost a VALU add
+// each -- all of it serial time next to the fp32 MFMAs.  base: one of four opaque lane bases (window x 128-byte parity), o0 / o1 in 256-byte units.
+__device__ __forceinline__ f32x2 lds_pair(unsigned int base, int o0, int o1) {
+    f32x2 v;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(base), "i"(o0), "i"(o1));
+    return v;
+}
+constexpr int WIN = 64000;                       // LDS window of one base register (250 x 256 bytes)
+#define WG_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }      // s_waitcnt vmcnt(n), other counters unconstrained
+#define WG_LDS_PTR(a) ((__attribute__((address_space(3))) void*)(size_t)(a))
+
 // One wave's share of the K loop over the groups [g0, g1) of this workgroup's slice.
 template <int WI, int WJ>
-__device__ __forceinline__ void wg_wave(const WgP& p, char* smem, const int tid, const int lane, const int co0, const int ci0, const int g0, const int g1,
-                                        f32x16 (&acc)[9][2], f32x4& bsum) {
-    constexpr bool XW = !(WI == 1 && WJ == 1);      // waves 0..2 stage x (144 threads: 18 pixels x 8 channel quads per row), all four stage dy
+__device__ __forceinline__ void wg_wave(const WgS p, char* smem, const int tid, const int lane, const int co0, const int ci0, const int g0, const int g1,
+                                        const bool want_db, f32x16 (&acc)[9][2], f32x2 (&bs)[2]) {
+    constexpr int WV = WI * 2 + WJ;
+    constexpr int NXI = WV < 3 ? 6 : 0, NDI = WV < 3 ? 4 : 8, NLD = NXI + NDI;      // global -> LDS copies per group: x rows / dy chunks of this wave
     const int l31 = lane & 31, h = lane >> 5;
     const int Ci4 = p.Ci * 4;
     const int n = g1 - g0;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dybytes, 0x00020000);
     const TfK tk = {opq2(4.f), opq2(-5.f), opq2(-4.f), opq2(2.f), opq2(-2.f)};
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned int lds0 = (unsigned int)(size_t)(lds_char*)smem;
 
-    // ---- staging constants of this thread ----
-    // x: pixel column c (0..17 of the strip, column 16 sx - 1 + c of the image, reflected at the image borders), channel quad q.  The row offset
-    // is scalar; the column part has four variants (strip at the left border / right border / both / neither): voffset stays non-negative.
-    const bool xact = tid < 144;
-    const int xc = tid >> 3, xq = tid & 7;
-    const unsigned int xvo_m = xact ? (unsigned int)(xc * Ci4 + xq * 16) : OOBV;
-    const unsigned int xvo_f = xact ? (unsigned int)((xc == 0 ? 1 : xc - 1) * Ci4 + xq * 16) : OOBV;
-    const unsigned int xvo_l = xact ? (unsigned int)((xc == 17 ? 15 : xc) * Ci4 + xq * 16) : OOBV;
-    const unsigned int xvo_fl = xact ? (unsigned int)((xc == 0 ? 1 : (xc == 17 ? 14 : xc - 1)) * Ci4 + xq * 16) : OOBV;
-    const int xlw = xact ? (xc + (xc >> 2)) * 128 + xq * 16 : 4 * 128 + xq * 16;      // (inactive lanes of wave 2: the empty slot)
-    const int dc = tid >> 4, dq = tid & 15;
-    const unsigned int dvo = (unsigned int)(dc * p.Co * 4 + dq * 16);
-    const int dlw = XB + dc * 256 + (dc >> 2) * 128 + dq * 16;
-    // lane parts of the LDS read addresses
-    const int xlb = h * 640 + l31 * 4;
-    const int dlb = XB + h * 1152 + l31 * 4;
+    // ---- staging: global -> LDS copies (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes = 1 KB of LDS in lane order, no registers) ----
+    // x: wave w < 3 copies chunk w (pieces 64 w .. 64 w + 63 = (slot, channel quad) pairs) of each of the six rows; a slot is pixel column
+    // c = slot - slot / 5 of the strip (image column 16 sx - 1 + c, reflected at the image borders) or empty (slot % 5 == 4, slots >= 22: the
+    // lane reads out of bounds = zeros).  The row offset is scalar; at the left / right image border the column part moves by a per-lane delta.
+    // (A select between precomputed variants AS VARIABLES became a select of closure field offsets -- a dynamically indexed closure that kept
+    //  every captured variable of the kernel in scratch memory; deltas added under a scalar condition do not.)
+    unsigned int xvo_m = OOBV;
+    int xd_first = 0, xd_last = 0;
+    if (NXI) {
+        const int slot = WV * 8 + (lane >> 3), xq = lane & 7, xc = slot - slot / 5;
+        if (slot % 5 != 4 && slot < 22) {
+            xvo_m = (unsigned int)(xc * Ci4 + xq * 16);
+            xd_first = xc == 0 ? Ci4 : -Ci4;          // strip at the left border: column -1 -> 1, the others relative to column 0
+            xd_last = xc == 17 ? -2 * Ci4 : 0;        // strip at the right border: column W -> W - 2
+        }
+    }
+    // dy: 20 chunks of [half][row][20 slots][8 quads]; waves 0..2 copy chunks w, w + 3, w + 6, w + 9, wave 3 chunks 12..19
+    unsigned int dvo[NDI];
+#pragma unroll
+    for (int i = 0; i < NDI; ++i) {
+        const int P = (WV < 3 ? WV + 3 * i : 12 + i) * 64 + lane;
+        const int half = P / 640, rem = P % 640, row = rem / 160, rem2 = rem % 160, slot = rem2 >> 3, q = rem2 & 7;
+        dvo[i] = slot % 5 == 4 ? OOBV : (unsigned int)((row * p.W + slot - slot / 5) * p.Co * 4 + half * 128 + q * 16);
+    }
+    // lane bases of the LDS reads, one register per 64 000-byte window and 128-byte parity (every read is base + immediate); opaque so that the
+    // compiler cannot re-associate them
+    unsigned int rb[6];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        rb[2 * w] = lds0 + h * 640 + l31 * 4 + w * WIN; rb[2 * w + 1] = rb[2 * w] + 128;
+        asm volatile("" : "+v"(rb[2 * w]), "+v"(rb[2 * w + 1]));
+    }
 
     // ---- the staging cursor: group cg = (image cb_, tile row cty, strip csx) ----
     int cg = g0, csx = g0 % p.TXS, cty = (g0 / p.TXS) % p.TY, cb_ = g0 / (p.TXS * p.TY);
-    int xso[6], dso[4];
-    unsigned int xvo = xvo_m;
-    auto setgroup = [&]() __attribute__((always_inline)) {
-        const bool first = csx == 0, last = csx == p.TXS - 1;
-        xvo = first ? (last ? xvo_fl : xvo_f) : (last ? xvo_l : xvo_m);
-        const int xcol = (first ? 0 : (16 * csx - 1) * Ci4) + ci0 * 4;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) xso[r] = __builtin_amdgcn_readfirstlane(((cb_ * p.H + reflg(4 * cty - 1 + r, p.H)) * p.W) * Ci4 + xcol);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dso[r] = __builtin_amdgcn_readfirstlane((((cb_ * p.H + 4 * cty + r) * p.W + 16 * csx) * p.Co + co0) * 4);
-    };
-    auto advance = [&]() __attribute__((always_inline)) {      // (past the last group: stay there, the loads are redundant)
-        if (cg + 1 < g1) {
-            ++cg;
-            if (++csx == p.TXS) { csx = 0; if (++cty == p.TY) { cty = 0; ++cb_; } }
-        }
-    };
-    f32x4 xr[6], dr[4];
-    auto issue = [&](int k) __attribute__((always_inline)) {
-        if (k < 6) { if (XW) xr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvo, xso[k], 0)); }
-        else dr[k - 6] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, dvo, dso[k - 6], 0));
-    };
-    auto wr = [&](int st, int k, bool count) __attribute__((always_inline)) {
-        if (k < 6) { if (XW) *reinterpret_cast<f32x4*>(smem + st * STAGE + k * XROW + xlw) = xr[k]; }
-        else {
-            *reinterpret_cast<f32x4*>(smem + st * STAGE + (k - 6) * DROW + dlw) = dr[k - 6];
-            if (count) bsum += dr[k - 6];      // bias gradient: this thread's pixel column and channel quad (count: uniform)
-        }
-    };
+    // copies of the cursor's group into stage st: NLD vector-memory instructions
+#define WG_STAGE(st)                                                                                                               \
+    do {                                                                                                                           \
+        const bool first_ = csx == 0, last_ = csx == p.TXS - 1;                                                                    \
+        if (NXI) {                                                                                                                 \
+            const unsigned int xvo = xvo_m + (unsigned int)((first_ ? xd_first : 0) + (last_ ? xd_last : 0));                      \
+            const int RS_ = p.W * Ci4;                                                                                             \
+            const int xb_ = (cb_ * p.H + 4 * cty - 1) * RS_ + (first_ ? 0 : (16 * csx - 1) * Ci4) + ci0 * 4;      /* row 4 ty - 1 */ \
+            _Pragma("unroll") for (int r = 0; r < NXI; ++r) {                                                                      \
+                int so = xb_ + r * RS_;                                                                                            \
+                if (r == 0) so = xb_ + (cty == 0 ? 2 * RS_ : 0);                          /* row -1 -> 1 */                        \
+                if (r == 5) so = xb_ + (cty == p.TY - 1 ? 3 * RS_ : 5 * RS_);             /* row H -> H - 2 */                     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, WG_LDS_PTR(lds0 + (st) * STAGE + r * XROW + WV * 1024), 16, xvo,      \
+                                                         __builtin_amdgcn_readfirstlane(so), 0, 0);                                \
+            }                                                                                                                      \
+        }                                                                                                                          \
+        const int db_ = __builtin_amdgcn_readfirstlane(((cb_ * p.H + 4 * cty) * p.W + 16 * csx) * p.Co * 4 + co0 * 4);             \
+        _Pragma("unroll") for (int i = 0; i < NDI; ++i)                                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, WG_LDS_PTR(lds0 + (st) * STAGE + XB + (WV < 3 ? WV + 3 * i : 12 + i) * 1024), 16, dvo[i], db_, 0, 0); \
+    } while (0)
+#define WG_ADVANCE()      /* (past the last group: stay there, the copies are redundant) */                                        \
+    do {                                                                                                                           \
+        if (cg + 1 < g1) {                                                                                                         \
+            ++cg;                                                                                                                  \
+            if (++csx == p.TXS) { csx = 0; if (++cty == p.TY) { cty = 0; ++cb_; } }                                                \
+        }                                                                                                                          \
+    } while (0)
 
     // ---- LDS reads of one group: the 4 x 4 block of dy (per 32-channel half i) and the 5 x 5 sub-patch of x of the lane's tile pair ----
+    auto rdp = [&](int A) __attribute__((always_inline)) {      // A: byte offset of the h = 0 element (a multiple of 128); the pair's second half: + 1280
+        const int par = (A >> 7) & 1, Ae = A - par * 128, w = Ae / WIN, o0 = (Ae - w * WIN) >> 8;
+        return lds_pair(rb[2 * w + par], o0, o0 + 5);
+    };
     f32x2 dyv[4][4];      // [pixel column][pixel row]
     auto rd_dy = [&](int st, int i, int cc) __attribute__((always_inline)) {
-        const char* src = smem + st * STAGE + dlb + i * 128 + cc * 256;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            dyv[cc][r] = (f32x2){*reinterpret_cast<const float*>(src + r * DROW), *reinterpret_cast<const float*>(src + r * DROW + 2304)};
+        for (int r = 0; r < 4; ++r) dyv[cc][r] = rdp(st * STAGE + XB + i * DHALF + r * DROW + cc * 128);
     };
     f32x2 d[5][5];        // [column][row]
     auto rd_x = [&](int st, int c) __attribute__((always_inline)) {
         const int cc = WJ + c;
-        const char* src = smem + st * STAGE + xlb + (cc + (cc >> 2)) * 128;
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
-            d[c][r] = (f32x2){*reinterpret_cast<const float*>(src + (WI + r) * XROW), *reinterpret_cast<const float*>(src + (WI + r) * XROW + 1280)};
+        for (int r = 0; r < 5; ++r) d[c][r] = rdp(st * STAGE + (WI + r) * XROW + (cc + (cc >> 2)) * 128);
     };
-    auto tf_dy = [&](f32x2 (&M)[9]) __attribute__((always_inline)) {      // 28 packed operations
+    // the hand-written reads are invisible to the compiler's wait-count insertion: wait here, tied to the values the next burst consumes
+    auto wait_dy = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dyv[0][0]), "+v"(dyv[0][1]), "+v"(dyv[0][2]), "+v"(dyv[0][3]), "+v"(dyv[1][0]), "+v"(dyv[1][1]), "+v"(dyv[1][2]), "+v"(dyv[1][3]),
+                       "+v"(dyv[2][0]), "+v"(dyv[2][1]), "+v"(dyv[2][2]), "+v"(dyv[2][3]), "+v"(dyv[3][0]), "+v"(dyv[3][1]), "+v"(dyv[3][2]), "+v"(dyv[3][3]));
+    };
+    auto wait_x = [&](int c0) __attribute__((always_inline)) {      // columns 0, 1, 2 (c0 = 0) or 3, 4 (c0 = 3)
+        if (c0 == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[0][4]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[1][2]), "+v"(d[1][3]),
+                           "+v"(d[1][4]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[2][2]), "+v"(d[2][3]), "+v"(d[2][4]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d[3][0]), "+v"(d[3][1]), "+v"(d[3][2]), "+v"(d[3][3]), "+v"(d[3][4]), "+v"(d[4][0]), "+v"(d[4][1]), "+v"(d[4][2]), "+v"(d[4][3]),
+                           "+v"(d[4][4]));
+    };
+    auto tf_dy = [&](f32x2 (&M)[9], int i, bool count) __attribute__((always_inline)) {      // 28 packed operations
         f32x2 t[3][4];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) a3g<WI>(tk, dyv[cc], t[0][cc], t[1][cc], t[2][cc]);
 #pragma unroll
         for (int il = 0; il < 3; ++il) a3g<WJ>(tk, t[il], M[il * 3], M[il * 3 + 1], M[il * 3 + 2]);
+        if (WV == 0 && count) {      // bias gradient: wave 0 of the workgroups of input-channel block 0 sums the raw block (count: uniform)
+            f32x2 sm = dyv[0][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) sm += dyv[e >> 2][e & 3];
+            bs[i] += sm;
+        }
     };
-    auto tf_x = [&](f32x2 (&V)[9]) __attribute__((always_inline)) {       // 48 packed operations
-        f32x2 t[3][5];
+    // B^T d B in two parts (48 packed operations): the column transform of columns 0..2 runs as its own burst as soon as they are read, so that
+    // only 38 registers of the sub-patch are ever live (t of three columns + two raw columns) instead of 50
+    f32x2 tx[3][5];
+    auto tf_x1 = [&](int c0, int c1) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < 5; ++c) bt3g<WI>(tk, d[c], t[0][c], t[1][c], t[2][c]);
+        for (int c = c0; c < c1; ++c) bt3g<WI>(tk, d[c], tx[0][c], tx[1][c], tx[2][c]);
+    };
+    auto tf_x2 = [&](f32x2 (&V)[9]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int il = 0; il < 3; ++il) bt3g<WJ>(tk, t[il], V[il * 3], V[il * 3 + 1], V[il * 3 + 2]);
+        for (int il = 0; il < 3; ++il) bt3g<WJ>(tk, tx[il], V[il * 3], V[il * 3 + 1], V[il * 3 + 2]);
     };
     // 18 accumulator tiles = 288 registers: 16 tiles fill the 256 AGPRs, the MFMAs of the last two are written in their VGPR form by hand
     auto mfma1 = [&](int fi, int i, float a, float b) __attribute__((always_inline)) {
@@ -189,68 +250,71 @@ __device__ __forceinline__ void wg_wave(const WgP& p, char* smem, const int tid,
         else acc[fi][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[fi][i], 0, 0, 0);
     };
 
-    // ---- prologue: groups 0 and 1 in LDS stages 0 and 1, group 2 in flight, operands of group 0 transformed ----
+    // ---- prologue: groups 0, 1, 2 copied to stages 0, 1, 2 (group 0 landed), operands of group 0 transformed ----
 #pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-        setgroup();
-#pragma unroll
-        for (int k = 0; k < 10; ++k) issue(k);
-#pragma unroll
-        for (int k = 0; k < 10; ++k) wr(gq, k, p.want_db && gq < n);
-        advance();
+    for (int gq = 0; gq < 3; ++gq) {
+        WG_STAGE(gq);
+        WG_ADVANCE();
     }
-    setgroup();
-#pragma unroll
-    for (int k = 0; k < 10; ++k) issue(k);
-    advance();
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * NLD));
+    WG_BARRIER();
     f32x2 Ma[2][9], Va[9], Mb[2][9], Vb[9];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) rd_dy(0, i, cc);
-        tf_dy(Ma[i]);
+        wait_dy();
+        tf_dy(Ma[i], i, want_db);
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) rd_x(0, c);
-    tf_x(Va);
+    wait_x(0); wait_x(3);
+    tf_x1(0, 5);
+    tf_x2(Va);
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(NLD));      // group 1 has landed ...
+    WG_BARRIER();                                    // ... for every wave
 
     // ---- main loop: iteration j multiplies the operands of group j (registers) while the strips of group j + 1 are read from stage (j + 1) % 4 and
-    // transformed in three bursts, the registers of group j + 2 are written to stage (j + 2) % 4 and the loads of group j + 3 are issued ----
-    auto iter = [&](int j, int R, int Ws, f32x2 (&Mc)[2][9], f32x2 (&Vc)[9], f32x2 (&Mn)[2][9], f32x2 (&Vn)[9]) __attribute__((always_inline)) {
-        const bool count = p.want_db && j + 2 < n;
+    // transformed in bursts, and group j + 3 is copied into stage (j + 3) % 4 (read last in iteration j - 2).  At the end of the iteration the
+    // wave waits for its copies of group j + 2 (all but the newest NLD), then the barrier publishes them: a copy has a whole iteration to land ----
+    auto iter = [&](int j, int R, f32x2 (&Mc)[2][9], f32x2 (&Vc)[9], f32x2 (&Mn)[2][9], f32x2 (&Vn)[9]) __attribute__((always_inline)) {
+        const bool count = want_db && j + 1 < n;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             mfma1(s, 0, Mc[0][s].x, Vc[s].x);
             mfma1(s, 1, Mc[1][s].x, Vc[s].x);
             mfma1(s, 0, Mc[0][s].y, Vc[s].y);
             mfma1(s, 1, Mc[1][s].y, Vc[s].y);
-            if (s == 2) { tf_dy(Mn[0]); __builtin_amdgcn_sched_barrier(0); }
-            if (s == 5) { tf_dy(Mn[1]); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 2) { wait_dy(); tf_dy(Mn[0], 0, count); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 5) { wait_dy(); tf_dy(Mn[1], 1, count); __builtin_amdgcn_sched_barrier(0); }
+            if (s == 7) { wait_x(0); tf_x1(0, 3); __builtin_amdgcn_sched_barrier(0); }
             if (s == 0) { rd_dy(R, 0, 0); rd_dy(R, 0, 1); }
             if (s == 1) { rd_dy(R, 0, 2); rd_dy(R, 0, 3); }
             if (s == 3) { rd_dy(R, 1, 0); rd_dy(R, 1, 1); }
             if (s == 4) { rd_dy(R, 1, 2); rd_dy(R, 1, 3); }
             if (s == 5) { rd_x(R, 0); rd_x(R, 1); }
-            if (s == 6) { rd_x(R, 2); rd_x(R, 3); }
-            if (s == 7) rd_x(R, 4);
-            wr(Ws, s, count);
-            if (s == 0) setgroup();
-            issue(s);
-            if (s == 8) { wr(Ws, 9, count); issue(9); }
+            if (s == 6) rd_x(R, 2);
+            if (s == 7) { rd_x(R, 3); rd_x(R, 4); }
+            if (s == 1) WG_STAGE((R + 2) & 3);
             __builtin_amdgcn_sched_barrier(0);
         }
-        tf_x(Vn);
-        advance();
+        wait_x(3);
+        tf_x1(3, 5);
+        tf_x2(Vn);
+        WG_ADVANCE();
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(NLD));
+        WG_BARRIER();
     };
     for (int j = 0; j < n; j += 4) {
-        iter(j, 1, 2, Ma, Va, Mb, Vb);
-        if (j + 1 < n) iter(j + 1, 2, 3, Mb, Vb, Ma, Va);
-        if (j + 2 < n) iter(j + 2, 3, 0, Ma, Va, Mb, Vb);
-        if (j + 3 < n) iter(j + 3, 0, 1, Mb, Vb, Ma, Va);
+        iter(j, 1, Ma, Va, Mb, Vb);
+        if (j + 1 < n) iter(j + 1, 2, Mb, Vb, Ma, Va);
+        if (j + 2 < n) iter(j + 2, 3, Ma, Va, Mb, Vb);
+        if (j + 3 < n) iter(j + 3, 0, Mb, Vb, Ma, Va);
     }
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));      // the redundant copies past the last group must not land in the epilogue's buffer
+#undef WG_STAGE
+#undef WG_ADVANCE
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) wino_wgrad_fused_kernel(WgP p) {
@@ -272,28 +336,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 bsum = (f32x4)(0.f);
-    WgP q = p;
-    q.want_db = (p.want_db && cib == 0) ? 1 : 0;
+    f32x2 bs[2] = {(f32x2)(0.f), (f32x2)(0.f)};
+    const bool want_db = p.want_db && cib == 0;
+    const WgS ps = {p.x, p.dy, (int)p.xbytes, (int)p.dybytes, p.H, p.W, p.Ci, p.Co, p.TY, p.TXS};
     if (g1 > g0) {
-        if (wave == 0) wg_wave<0, 0>(q, smem, tid, lane, co0, ci0, g0, g1, acc, bsum);
-        else if (wave == 1) wg_wave<0, 1>(q, smem, tid, lane, co0, ci0, g0, g1, acc, bsum);
-        else if (wave == 2) wg_wave<1, 0>(q, smem, tid, lane, co0, ci0, g0, g1, acc, bsum);
-        else wg_wave<1, 1>(q, smem, tid, lane, co0, ci0, g0, g1, acc, bsum);
+        if (wave == 0) wg_wave<0, 0>(ps, smem, tid, lane, co0, ci0, g0, g1, want_db, acc, bs);
+        else if (wave == 1) wg_wave<0, 1>(ps, smem, tid, lane, co0, ci0, g0, g1, want_db, acc, bs);
+        else if (wave == 2) wg_wave<1, 0>(ps, smem, tid, lane, co0, ci0, g0, g1, want_db, acc, bs);
+        else wg_wave<1, 1>(ps, smem, tid, lane, co0, ci0, g0, g1, want_db, acc, bs);
     }
 
     // ---- epilogue: bias partial (16 pixel columns per channel quad, summed in order), then the frequency exchange and G^T dU G ----
     float* Es = reinterpret_cast<float*>(smem);
-    if (q.want_db) {
+    if (want_db) {      // wave 0's lanes hold, per 32-channel half, the column sums over their two tiles of every group: add the lane halves
         __syncthreads();
-        *reinterpret_cast<f32x4*>(Es + tid * 4) = bsum;      // [pixel column dc][channel quad dq][4]
+        if (wave == 0) { Es[lane] = bs[0].x + bs[0].y; Es[64 + lane] = bs[1].x + bs[1].y; }
         __syncthreads();
-        if (tid < 64) {
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) s += Es[c * 64 + tid];
-            p.partdb[(size_t)slice * p.Co + co0 + tid] = s;
-        }
+        if (tid < 64) p.partdb[(size_t)slice * p.Co + co0 + tid] = Es[(tid >> 5) * 64 + (tid & 31)] + Es[(tid >> 5) * 64 + 32 + (tid & 31)];
     }
     const int wi = wave >> 1, wj = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
@@ -368,8 +427,8 @@ WgPlan wg_plan(const ConvGeom& g) {
 
 }  // namespace
 
-// tuning / test knob behind aclgan_set_tuning("wino_wgrad_fused", v): 0 = the pipeline of conv_wino.hip, 1 = the fused kernel where it pays,
-// 2 = wherever the shape is eligible; returns the previous value.  ACLGAN_WINO_WGRAD_FUSED sets the default.
+// tuning / test knob behind aclgan_set_tuning("wino_wgrad_fused", v): 0 = the pipeline of conv_wino.hip, 1 / 2 = the fused kernel wherever the
+// shape is eligible (it pays at every grid size measured); returns the previous value.  ACLGAN_WINO_WGRAD_FUSED sets the default.
 int wino_wgrad_fused_mode() {
     if (g_wgrad_fused < 0) { const char* e = getenv("ACLGAN_WINO_WGRAD_FUSED"); g_wgrad_fused = e ? atoi(e) : 1; if (g_wgrad_fused < 0 || g_wgrad_fused > 2) g_wgrad_fused = 1; }
     return g_wgrad_fused;
@@ -377,19 +436,23 @@ int wino_wgrad_fused_mode() {
 int set_wino_wgrad_fused(int v) { const int old = wino_wgrad_fused_mode(); g_wgrad_fused = (v < 0 || v > 2) ? 1 : v; return old; }
 
 // 3x3 stride-1 reflect-pad-1 layers with W a multiple of 16, H of 4, Cout of 64, Cin of 32
+namespace {
+bool wg_shape_ok(const ConvGeom& g) {
+    return g.k == 3 && g.s == 1 && g.p == 1 && g.up == 0 && g.Ho % 4 == 0 && g.Wo % 16 == 0 && g.Wo >= 16 && g.Co % WCO == 0 && g.Ci % WCI == 0 && g.Hi >= 4 &&
+           g.B >= 1 && (long long)g.B * g.Hi * g.Wi * std::max(g.Ci, g.Co) * 4 < 0x7fffffe0ll;
+}
+}  // namespace
 bool wino_wgrad_fused_ok(const ConvGeom& g) {
     const int m = wino_wgrad_fused_mode();
     if (m == 0) return false;
-    const bool shape = g.k == 3 && g.s == 1 && g.p == 1 && g.up == 0 && g.Ho % 4 == 0 && g.Wo % 16 == 0 && g.Co % WCO == 0 && g.Ci % WCI == 0 && g.Hi >= 4 &&
-                       (long long)g.B * g.Hi * g.Wi * std::max(g.Ci, g.Co) * 4 < 0x7fffffe0ll;
-    if (!shape || m == 2) return shape;
-    const WgPlan q = wg_plan(g);
-    // cost model (microseconds): a workgroup walks gper groups at ~1.45 us each; the pipeline: conv_wino.hip's five launches
-    const double t_fused = (25.0 + 1.45 * q.gper) * std::ceil((double)q.nblk * q.ks / 256.0) + 8.0;
-    const double t_pipe = 60.0 + 0.066 * (double)g.B * q.TY * q.TXS * 4 * ((double)g.Ci * g.Co / 65536.0);
-    return t_fused <= t_pipe;
+    const bool shape = wg_shape_ok(g);
+    // MEASURED (scripts/probe_wgrad_fused.py, 256 -> 256 channels on 64 x 64 maps, back to back, finish launch included): fused 35 / 46 / 57 / 67 / 91 /
+    // 116 us at B = 1 / 2 / 3 / 4 / 6 / 8 against 57 / 80 / 99 / 117 / 127 / 176 us for the pipeline of conv_wino.hip: the K split adapts the
+    // workgroup count to the tile count, so unlike the fused forward kernel there is no small-grid regime where the pipeline wins.
+    return shape;
 }
 size_t wino_wgrad_fused_scratch_bytes(const ConvGeom& g) {
+    if (!wg_shape_ok(g)) return 0;
     const WgPlan q = wg_plan(g);
     return (((size_t)q.ks * g.Co * 9 * g.Ci * 4 + 255) & ~(size_t)255) + (((size_t)q.ks * g.Co * 4 + 255) & ~(size_t)255) + 256;
 }

@@ -156,6 +156,46 @@ def test_winograd_fused_kernel(L, case):
     assert rel_err(out[2][0], out[0][0]) < 5e-5 and rel_err(out[2][1], out[0][1]) < 5e-5
 
 
+WGRAD_FUSED_CASES = [(1, 16, 16, 64, 64), (2, 16, 32, 64, 64), (1, 8, 32, 64, 128), (3, 20, 48, 64, 64), (7, 12, 16, 128, 64), (2, 64, 64, 256, 256), (5, 32, 32, 128, 128)]
+
+
+@pytest.mark.parametrize("case", WGRAD_FUSED_CASES)
+def test_winograd_wgrad_fused_kernel(L, case):
+    """csrc/conv_wino_wgrad_fused.hip (round 4): the weight / bias gradient of the 3x3 ResBlock convolutions with both Winograd transforms done in
+    registers on the way into the MFMAs (one kernel + one ordered finish launch instead of seven launches and 150 MB of planes).  Against the
+    oracle's autograd (networks.py:297-310 Conv2dBlock, zero-initialised and NON-zero gradient buffers: the kernels accumulate), against the
+    pipeline of conv_wino.hip, run to run bit-identical (ordered K slices); shapes with one strip per row (both image borders in one strip),
+    a single group per K slice (the small shapes), K slices of unequal length (5 x 8 x 2 = 80 groups in 27 slices of 3, 3, .., 2), the step's shape."""
+    from gpu_util import conv_desc, nhwc, ohwi, rel_err
+    import ctypes as C
+    B, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Ci, H, W, generator=g); dy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True); b = torch.zeros(Co, requires_grad=True)
+    O.conv_block(x, w, b, 1, 1, "none").backward(dy)
+    dw0 = torch.randn(Co, 3, 3, Ci, generator=g) * 0.1; db0 = torch.randn(Co, generator=g)
+    d = conv_desc(L, B, H, W, Ci, Co, 3, 1, 1, 0, "none")
+    xg, dyg = nhwc(x).cuda(), nhwc(dy).cuda()
+    scratch = torch.empty(L.lib.aclgan_conv2d_wgrad_scratch_bytes(C.byref(d)) // 4 + 16, device="cuda")
+    out = {}
+    old = L.lib.aclgan_set_tuning(b"wino_wgrad_fused", 0)
+    try:
+        for v in (0, 2, 3):      # 3 = the fused kernel a second time
+            L.lib.aclgan_set_tuning(b"wino_wgrad_fused", min(v, 2))
+            dw, db = dw0.clone().cuda(), db0.clone().cuda()
+            n0 = L.lib.aclgan_launch_count()
+            L.check(L.lib.aclgan_conv2d_wgrad_ws(C.byref(d), L.ptr(xg), L.ptr(dyg), L.ptr(dw), L.ptr(db), L.ptr(scratch), L.stream_ptr()), "conv2d_wgrad_ws")
+            out[v] = (dw.cpu() - dw0, db.cpu() - db0, L.lib.aclgan_launch_count() - n0, dw.cpu(), db.cpu())
+    finally:
+        L.lib.aclgan_set_tuning(b"wino_wgrad_fused", old)
+    for v in (0, 2):
+        assert rel_err(out[v][0], ohwi(w.grad)) < 5 * TOL and rel_err(out[v][1], b.grad) < 5 * TOL, (v, rel_err(out[v][0], ohwi(w.grad)), rel_err(out[v][1], b.grad))
+    assert out[2][2] == 2, "the forced mode did not take the fused kernel (%d launches)" % out[2][2]
+    assert torch.equal(out[2][3], out[3][3]) and torch.equal(out[2][4], out[3][4]), "the fused weight gradient is not reproducible run to run"
+    if Ci % 64 == 0:      # (below that the mode-0 path is the direct kernel, not the Winograd pipeline)
+        assert rel_err(out[2][0], out[0][0]) < 5e-5
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(L, case):
     from gpu_util import conv_desc, gpu_conv_dgrad, nhwc, nchw, ohwi, rel_err
