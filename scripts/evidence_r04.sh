@@ -34,6 +34,12 @@ if has bench16; then
     $B --dtype fp16 > $O/bench_256_fp16_b32.json 2>/dev/null; summ $O/bench_256_fp16_b32.json | tee -a $O/progress.log
 fi
 if has benchdet; then $B --deterministic > $O/bench_256_fp32_deterministic.json 2>/dev/null; summ $O/bench_256_fp32_deterministic.json | tee -a $O/progress.log; fi
+if has benchab; then      # what the fused weight gradient and the backward side stream are worth, alone and together
+    ACLGAN_SIDE_STREAM=0 $B --no-launch-floor > $O/bench_256_fp32_side_stream_off.json 2>/dev/null; summ $O/bench_256_fp32_side_stream_off.json | tee -a $O/progress.log
+    ACLGAN_WINO_WGRAD_FUSED=0 $B --no-launch-floor > $O/bench_256_fp32_pipeline_wgrad.json 2>/dev/null; summ $O/bench_256_fp32_pipeline_wgrad.json | tee -a $O/progress.log
+    ACLGAN_WINO_WGRAD_FUSED=0 ACLGAN_SIDE_STREAM=0 $B --no-launch-floor > $O/bench_256_fp32_pipeline_wgrad_side_stream_off.json 2>/dev/null; summ $O/bench_256_fp32_pipeline_wgrad_side_stream_off.json | tee -a $O/progress.log
+fi
+if has probewg; then (timeout 300 python scripts/probe_wgrad_fused.py 2>&1 | grep -v amdgpu.ids) > $O/probe_wgrad_fused.txt; tail -9 $O/probe_wgrad_fused.txt | tee -a $O/progress.log; fi
 if has benchold; then ACLGAN_WINO_FUSED=0 $B > $O/bench_256_fp32_three_launch_winograd.json 2>/dev/null; summ $O/bench_256_fp32_three_launch_winograd.json | tee -a $O/progress.log; fi
 trace() {   # tag, bench args (env passes through)
     rm -rf /tmp/prof_$1
@@ -70,6 +76,17 @@ if has pmcfused; then
     timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS -d /tmp/pmcf_sq2 -o p -- python scripts/probe_wino.py fwd > /dev/null 2>&1
     python scripts/pmc_dump.py $(find /tmp/pmcf_sq2 -name "*.db" | head -1) wino_fused >> $O/pmc_wino_fused_sq.txt 2>&1
     cut -c 1-130 $O/pmc_wino_fused_sq.txt | tee -a $O/progress.log
+fi
+if has pmcwgrad; then
+    for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/pmcw_$c
+        timeout 300 rocprofv3 --pmc $c -d /tmp/pmcw_$c -o p -- python scripts/probe_wino.py wgrad > $O/pmcw_$c.log 2>&1
+    done
+    python scripts/pmc_kernel_traffic.py $(find /tmp/pmcw_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmcw_WRITE_SIZE -name "*.db" | head -1) wino_wgrad_fused_kernel $O/pmc_wino_wgrad_fused.json | cut -c 1-300 | tee -a $O/progress.log
+    rm -rf /tmp/pmcw_sq
+    timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT -d /tmp/pmcw_sq -o p -- python scripts/probe_wino.py wgrad > /dev/null 2>&1
+    python scripts/pmc_dump.py $(find /tmp/pmcw_sq -name "*.db" | head -1) wgrad_fused > $O/pmc_wino_wgrad_fused_sq.txt 2>&1
+    cut -c 1-130 $O/pmc_wino_wgrad_fused_sq.txt | tee -a $O/progress.log
 fi
 if has roctx; then
     rm -rf /tmp/prof_roctx
