@@ -187,6 +187,12 @@ struct FwdSP {
 // the consumers need next: s_waitcnt vmcnt((S - 2) x pieces)).
 constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }      // s_waitcnt vmcnt(n), other counters unconstrained
 #define WG_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+// Barrier that PUBLISHES global -> LDS copies: every wave waits for its own copies first.  __syncthreads() alone does not guarantee that: to
+// the compiler an LDS-DMA load is a load, its release fence does not wait for loads, and the wait it inserts for the LDS reads that follow
+// covers only the copies THIS wave's reads may alias -- the 256 x 256 forward tile (8 copies per wave and k-tile) came out as
+// `s_waitcnt vmcnt(2); s_barrier`: another wave's reads raced the last two copies (round 4: 1 launch in 3 000 differed, found by
+// tests/test_gpu_ops16s.py::test_conv_fwd16s_epilogue_statistics, reproduced by scripts/debug/stress_stats16s.py).
+#define DMA_SYNCTHREADS() do { __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); __syncthreads(); } while (0)
 
 template <class T, int WM, int WN, int TN, int NBUF, int NP>
 __global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : (NBUF == 1 ? 4 : 2)) conv_fwd16s_kernel(FwdSP p) {
@@ -286,14 +292,14 @@ __global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : (NBUF == 1 ? 4 :
             issue(0, 0);
             for (int kt = 0; kt < nk; ++kt) {
                 const int cur = kt & 1;
-                __syncthreads();                       // (vmcnt(0) +) barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
+                DMA_SYNCTHREADS();                     // vmcnt(0) + barrier: tile kt has landed for every wave, buffer cur ^ 1 is free
                 if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
                 mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
             }
         } else {
             for (int kt = 0; kt < nk; ++kt) {
                 issue(kt, 0);
-                __syncthreads();                       // tile kt has landed
+                DMA_SYNCTHREADS();                     // tile kt has landed
                 mma_tile<T, TM, TN>(smem + (wm * 64) * ROWB, smem + A_BYTES + (wn * TN * 32) * ROWB, lane, acc);
                 __syncthreads();                       // every wave is done reading: the buffer may be refilled
             }
@@ -551,7 +557,7 @@ __global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : 2) conv_dgrad16s
             issue(0, 0);
             for (int kt = 0; kt < nk; ++kt) {
                 const int cur = kt & 1;
-                __syncthreads();
+                DMA_SYNCTHREADS();
                 if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
                 mma_tile<T, TM, TN>(smem + cur * A_BYTES + (wm * 64) * ROWB, smem + NBUF * A_BYTES + cur * B_BYTES + (wn * TN * 32) * ROWB, lane, acc);
             }
@@ -713,7 +719,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad16s_kernel(WgSP p) {
         for (int n = 0; n < 4; ++n) piece(0, n, 0);
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
-            __syncthreads();
+            DMA_SYNCTHREADS();
             if (kt + 1 < nkt) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) piece(kt + 1, n, cur ^ 1);

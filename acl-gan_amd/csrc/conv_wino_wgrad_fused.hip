@@ -13,13 +13,14 @@
 //   A operand = dM: every lane reads the 4 x 4 block of dy of ITS tile pair and output channel from LDS and applies A . A^T restricted to the
 //               wave's 3 x 3 frequencies: 28 packed operations per 32-channel half.
 //   B operand = V: the 5 x 5 sub-patch of x of the tile pair and input channel, B^T . B restricted likewise: 48 packed operations.
-//   Raw dy / x strips are staged global -> registers -> LDS ahead (three LDS stages); all addresses are SGPR row offsets
-//   (computed per group on the scalar unit: batch, tile row, reflection) + one constant lane offset.
+//   Raw dy / x strips are copied global -> LDS directly (buffer_load_dwordx4 ... lds: no staging registers, no ds_write) two groups ahead
+//   through four LDS stages; all addresses are SGPR row offsets (computed per group on the scalar unit: image, tile row, reflection) + one
+//   constant lane offset.
 //   epilogue = the 36 frequencies of a (co, ci) pair live in four waves: exchange through LDS (two passes of 144 KB), G^T dU G per thread,
-//              partial dw of this K slice stored as [slice][co][ky][kx][ci]; the bias gradient (column sums of dy) is accumulated from the
-//              staging registers by the workgroups of input-channel block 0.  wgrad_fused_finish_kernel adds the slices in order.
+//              partial dw of this K slice stored as [slice][co][ky][kx][ci]; the bias gradient (column sums of dy) is accumulated by wave 0 of the
+//              workgroups of input-channel block 0 from the blocks it reads anyway.  wgrad_fused_finish_kernel adds the slices in order.
 //
-// LDS layout of a stage (bytes): x strip  [6 rows][22 pixel slots][32 ci] floats, slot(c) = c + (c >> 2)  (one empty slot after every 4 pixels);
+// LDS layout of a stage (bytes): x strip  [6 rows][24 pixel slots, 22 used][32 ci] floats, slot(c) = c + (c >> 2)  (one empty slot after every 4 pixels);
 //                                dy strip [2 co halves][4 rows][20 pixel slots][32 co] floats, the same slot rule.
 // A tile is 640 bytes wide in both: the two lane halves (tiles h = 0 / 1) are 128 B (mod 256) apart: conflict-free; tiles h and h + 2 are
 // 1280 B = 5 x 256 apart: one ds_read2st64_b32 fetches the packed pair; one lane base register serves both strips.

@@ -303,6 +303,11 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
  * products on the bf16 matrix cores (fp32-accurate, see aclgan_gemm_slices_x3), 0 (default) = on the fp32 MFMA kernel.
  * key "dgrad16s_direct": 1 = aclgan_conv2d_dgrad16s stores pixels without mirrored partners straight into a 16-bit dx (bit-identical,
  * measured neutral), 0 (default) = every pixel through the padded scratch and the ordered fold.
+ * key "wino_fused" (round 4): 0 = the 3x3 ResBlock / sub-pixel-phase convolutions never take the one-launch Winograd kernel
+ * (csrc/conv_wino_fused.hip), 1 (default) = where its cost model says it pays, 2 = wherever the shape is eligible.
+ * key "wino_wgrad_fused" (round 4): 0 = their weight gradient runs as the seven-launch pipeline of csrc/conv_wino.hip, 1 (default) / 2 = as the
+ * one-kernel Winograd weight gradient (csrc/conv_wino_wgrad_fused.hip) wherever the shape is eligible (W a multiple of 16, H of 4, Cout of 64,
+ * Cin of 32).
  * Returns the previous value, -1 for an unknown key.  Not thread-safe against running launches. */
 int aclgan_set_tuning(const char* key, int value);
 /* The same launch with the normalisation statistics taken from its epilogue (round 3; replaces the norm_stats pass over y that
