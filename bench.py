@@ -323,6 +323,9 @@ def main():
     from aclgan_amd.trainer import aclgan_Trainer
 
     cfg["display_size"] = 1
+    if os.environ.get("ACLGAN_BENCH_TEST_WIDTH"):      # test hook (tests/test_gpu_ddp.py): the control flow of N ranks sharing one GPU over gloo, with
+        tw = int(os.environ["ACLGAN_BENCH_TEST_WIDTH"])     # networks narrow enough that gloo's host-side all-reduce does not dominate the test's wall time
+        cfg["gen"].update(dim=tw, mlp_dim=2 * tw); cfg["dis"].update(dim=tw)
     torch.manual_seed(0)       # (replicas are made identical by the trainer's rank-0 broadcast, not by this seed)
     tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, deterministic=True if args.deterministic else None,
                         hip_graph=True if args.graph else None)
@@ -490,7 +493,8 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic U(-1,1) A/B batches, reference init statistics, seeded z",
-            "config": {"workload": "%s %dx%d %s, batch=%d per GPU: dis_update + gen_update (fwd+bwd+Adam each)" % (name, S, S, args.dtype, B),
+            "config": {"workload": "%s %dx%d %s, batch=%d per GPU: dis_update + gen_update (fwd+bwd+Adam each)%s" %
+                                   (name, S, S, args.dtype, B, " [TEST WIDTH %s: not a benchmark]" % os.environ["ACLGAN_BENCH_TEST_WIDTH"] if os.environ.get("ACLGAN_BENCH_TEST_WIDTH") else ""),
                        "config_file": os.path.relpath(cfg_path, ROOT),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "rccl_world_size": dist.get_world_size() if use_dist else 1,
                        "dist_backend": dist.get_backend() if use_dist else None, "replicas_identical": replicas_identical,

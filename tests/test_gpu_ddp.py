@@ -102,7 +102,7 @@ def _bench_shared(args, timeout=900):
     import sys
     from conftest import ROOT
     env = dict(os.environ)
-    env.update(ACLGAN_DIST_BACKEND="gloo", ACLGAN_BENCH_SHARE_GPU="1")
+    env.update(ACLGAN_DIST_BACKEND="gloo", ACLGAN_BENCH_SHARE_GPU="1", ACLGAN_BENCH_TEST_WIDTH="16")      # (narrow networks: gloo reduces through the host)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ACLGAN_BENCH_FORCE_DIST", "ACLGAN_DDP_OVERLAP"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
