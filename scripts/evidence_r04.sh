@@ -52,6 +52,7 @@ trace() {   # tag, bench args (env passes through)
 if has trace; then trace 256_fp32 ""; fi
 if has trace_ss0; then ACLGAN_SIDE_STREAM=0 trace 256_fp32_side_stream_off ""; fi
 if has trace16; then trace 256_bf16 "--dtype bf16"; fi
+if has trace512; then trace 512_fp32 "--config configs/glasses_removal.yaml"; fi
 traffic() {   # dtype size batch
     export PROBE_STEP_JSON=$O/probe_step_$1_$2_b$3.json
     for c in FETCH_SIZE WRITE_SIZE; do
