@@ -76,6 +76,28 @@ def test_conv_descriptor_validation_without_gpu():
     assert L.lib.aclgan_norm_scratch_bytes(2, 64, 16) > 0
 
 
+def test_weight_gradient_scratch_covers_both_winograd_paths_without_gpu():
+    """aclgan_conv2d_wgrad_scratch_bytes is sized BEFORE the tuning switch may change: it must cover the one-kernel Winograd weight gradient
+    (csrc/conv_wino_wgrad_fused.hip: ordered K-slice partials [ks][Cout][9][Cin] + bias partials) as well as the seven-launch pipeline, for
+    every batch size; the switch round-trips its previous value."""
+    L = _lib()
+    old = L.lib.aclgan_set_tuning(b"wino_wgrad_fused", 0)
+    assert old in (0, 1, 2)
+    try:
+        for B in (1, 3, 8):
+            d = L.ConvDesc(B, 64, 64, 256, 256, 3, 1, 1, 0, 0)
+            L.lib.aclgan_set_tuning(b"wino_wgrad_fused", 0)
+            pipe = L.lib.aclgan_conv2d_wgrad_scratch_bytes(C.byref(d))
+            assert L.lib.aclgan_set_tuning(b"wino_wgrad_fused", 2) == 0
+            both = L.lib.aclgan_conv2d_wgrad_scratch_bytes(C.byref(d))
+            assert both == pipe                              # (sized for either path whatever the switch says)
+            groups = B * 16 * 4                              # strips of four 4x4 tiles
+            ks = max(1, min(groups, 64, 256 // 32))          # 32 channel blocks of 64 x 32
+            assert both >= ks * 256 * 9 * 256 * 4 + ks * 256 * 4
+    finally:
+        L.lib.aclgan_set_tuning(b"wino_wgrad_fused", old)
+
+
 def test_product_path_refuses_to_run_without_gpu():
     import torch
     if torch.cuda.is_available():
