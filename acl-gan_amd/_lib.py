@@ -115,6 +115,8 @@ SIGNATURES = {
     "aclgan_conv16s_ok": (ci, [C.POINTER(ConvDesc), ci]),
     "aclgan_conv2d_fwd16s": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp]),
     "aclgan_set_tuning": (ci, [C.c_char_p, ci]),
+    "aclgan_tuning": (ci, [C.c_char_p, ci, C.POINTER(ci)]),
+    "aclgan_check_workspace": (ci, [vp, ci, ci, ci]),
     "aclgan_conv2d_fwd16s_stats_chunk": (ci, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_fwd16s_stats": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp, vp]),
     "aclgan_conv2d_dgrad16s_scratch_bytes": (sz, [C.POINTER(ConvDesc)]),
@@ -147,6 +149,7 @@ SIGNATURES = {
     "aclgan_focus_blend_bwd": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
     "aclgan_focus_translation_nchw": (ci, [vp, i64, vp, i64, vp, i64, vp, ci, ci, vp]),
     "aclgan_lsgan_loss": (ci, [vp, ci, cf, cf, vp, vp, cf, vp]),
+    "aclgan_lsgan_loss_multi": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     "aclgan_l1_loss": (ci, [vp, ci, vp, i64, vp, vp, cf, ci, vp]),
     "aclgan_focus_loss_scratch_bytes": (sz, [i64]),
     "aclgan_focus_loss": (ci, [vp, i64, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp]),

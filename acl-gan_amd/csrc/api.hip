@@ -5,11 +5,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <vector>
 
 namespace aclgan {
 
 static thread_local char g_err[512] = "";
-long long g_launches = 0;
+std::atomic<long long> g_launches{0};
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -21,6 +23,20 @@ int hip_fail(hipError_t e, const char* what) {
     set_error("%s: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
     return ACLGAN_EHIP;
 }
+
+// scheduler switches (common.h)
+static std::atomic<int> g_lanes{-1}, g_u_batch{-1};
+static std::atomic<long long> g_tuning_epoch{0};
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+int lanes_setting() { int v = g_lanes.load(); if (v < 0) { v = std::max(1, std::min(4, env_int("ACLGAN_LANES", 2))); g_lanes.store(v); } return v; }
+int set_lanes(int v) { const int old = lanes_setting(); g_lanes.store(std::max(1, std::min(4, v))); return old; }
+int u_batch_setting() { int v = g_u_batch.load(); if (v < 0) { v = env_int("ACLGAN_U_BATCH", 1) ? 1 : 0; g_u_batch.store(v); } return v; }
+int set_u_batch(int v) { const int old = u_batch_setting(); g_u_batch.store(v ? 1 : 0); return old; }
+static std::atomic<int> g_fault_at{-1};
+int fault_at_setting() { return g_fault_at.load(); }
+int set_fault_at(int v) { return g_fault_at.exchange(v); }
+long long tuning_epoch() { return g_tuning_epoch.load(); }
+void bump_tuning_epoch() { ++g_tuning_epoch; }
 
 static int g_determ = -1;
 bool deterministic() {
@@ -247,14 +263,27 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
     if (rc == ACLGAN_EUNSUPPORTED) set_error("conv2d_fwd16s: no 16-bit-storage kernel for this shape (no upsample, Cin and Cout multiples of 64, grid >= 96 tiles)");
     return rc;
 }
+// status in the return value, the previous setting through `previous` (optional): an unknown key is ACLGAN_EINVAL, never a value
+int aclgan_tuning(const char* key, int value, int* previous) {
+    ACL_REQUIRE(key, "aclgan_tuning: null key");
+    int old = 0;
+    if (!strcmp(key, "glds_tile")) old = set_glds_tile(value);
+    else if (!strcmp(key, "wino_x3")) old = set_wino_x3(value);
+    else if (!strcmp(key, "wino_fused")) old = set_wino_fused(value);
+    else if (!strcmp(key, "wino_wgrad_fused")) old = set_wino_wgrad_fused(value);
+    else if (!strcmp(key, "dgrad16s_direct")) old = set_dgrad16s_direct(value);
+    else if (!strcmp(key, "lanes")) old = set_lanes(value);
+    else if (!strcmp(key, "u_batch")) old = set_u_batch(value);
+    else if (!strcmp(key, "fault_at")) old = set_fault_at(value);
+    else { set_error("aclgan_tuning: unknown key '%s'", key); return ACLGAN_EINVAL; }
+    bump_tuning_epoch();
+    if (previous) *previous = old;
+    return ACLGAN_OK;
+}
+// (round 3 form, kept: the previous value in the return value, -1 for an unknown key)
 int aclgan_set_tuning(const char* key, int value) {
-    if (key && !strcmp(key, "glds_tile")) return set_glds_tile(value);
-    if (key && !strcmp(key, "wino_x3")) return set_wino_x3(value);
-    if (key && !strcmp(key, "wino_fused")) return set_wino_fused(value);
-    if (key && !strcmp(key, "wino_wgrad_fused")) return set_wino_wgrad_fused(value);
-    if (key && !strcmp(key, "dgrad16s_direct")) return set_dgrad16s_direct(value);
-    set_error("aclgan_set_tuning: unknown key");
-    return -1;
+    int old = 0;
+    return aclgan_tuning(key, value, &old) == ACLGAN_OK ? old : -1;
 }
 int aclgan_conv2d_fwd16s_stats_chunk(const aclgan_conv_desc* d) { ConvGeom g; return (d && make_geom(d, &g) == 0 && conv16_eligible(g, 0)) ? conv_fwd16s_stats_chunk(g) : 0; }
 int aclgan_conv2d_fwd16s_stats(const aclgan_conv_desc* d, int dtype, const void* x16, const void* w16, const float* bias, void* y, int y_storage,
@@ -343,6 +372,17 @@ int aclgan_focus_translation_nchw(const float* fg, int64_t fg_bstride, const flo
 int aclgan_lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, void* stream) {
     ACL_REQUIRE(o && n > 0 && loss_slot, "lsgan_loss: bad arguments");
     return lsgan_loss(o, n, target, weight, loss_slot, d_o, gscale, (hipStream_t)stream);
+}
+int aclgan_lsgan_loss_multi(const float* const* o, const int* n, const float* target, const float* weight, float* const* loss_slot,
+                            float* const* d_o, const float* gscale, int nterms, void* stream) {
+    ACL_REQUIRE(o && n && target && weight && loss_slot && gscale && nterms >= 1 && nterms <= 1024, "lsgan_loss_multi: bad arguments");
+    std::vector<LsganTerm> t((size_t)nterms);
+    for (int i = 0; i < nterms; ++i) {
+        ACL_REQUIRE(o[i] && n[i] > 0 && loss_slot[i], "lsgan_loss_multi: bad term %d", i);
+        t[i].o = o[i]; t[i].d_o = d_o ? d_o[i] : nullptr; t[i].slot = loss_slot[i]; t[i].n = n[i];
+        t[i].target = target[i]; t[i].weight = weight[i]; t[i].gscale = gscale[i];
+    }
+    return lsgan_loss_batch(t.data(), nterms, (hipStream_t)stream);
 }
 int aclgan_l1_loss(const float* a, int a_channels, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate,
                    void* stream) {

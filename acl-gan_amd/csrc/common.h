@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <atomic>
 #include "../../include/aclgan_hip.h"
 
 namespace aclgan {
@@ -12,7 +13,7 @@ void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 
 // kernel launches issued by this library since load (measurement support: aclgan_launch_count; bench.py reports launches per step)
-extern long long g_launches;
+extern std::atomic<long long> g_launches;
 
 #define ACL_CHECK_LAUNCH(what)                                           \
     do {                                                                 \
@@ -37,6 +38,20 @@ int reduce_slices_ordered(const float* part, int64_t n, int nslices, float* out,
 // db[c] += sum over the M rows of dy[M][C], reproducible: row chunks -> part [chunks][C] -> ordered.  part: colsum_ordered_bytes(M, C)
 size_t colsum_ordered_bytes(int64_t M, int C);
 int colsum_ordered(const float* dy, float* db, int64_t M, int C, void* part, hipStream_t st);
+
+// Scheduler switches (aclgan_tuning / environment), read once per update:
+//   lanes (ACLGAN_LANES, default 2): HIP streams the independent branches of an update are spread over (engine.hip); 1 = one queue
+//   u_batch (ACLGAN_U_BATCH, default 1): batched Winograd filter transforms at the start of an update
+int lanes_setting();
+int set_lanes(int v);            // returns the previous value
+int u_batch_setting();
+int set_u_batch(int v);
+//   fault_at (test hook, default -1 = off): the backward replay fails with ACLGAN_EHIP after its fault_at-th closure has been enqueued --
+//   the error path (lanes and side stream drained before the caller is told) is testable without breaking the GPU
+int fault_at_setting();
+int set_fault_at(int v);
+// every aclgan_tuning call bumps this: cached results that depend on a switch (workspace checks) are keyed by it
+long long tuning_epoch();
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -92,6 +107,15 @@ struct WinoUCache { void* user; float* (*lookup)(void* user, const float* w, int
 void set_wino_ucache(const WinoUCache* c);      // thread-local; nullptr = off (operator-level calls)
 const WinoUCache* wino_ucache();
 size_t conv_wino_u_bytes(const ConvGeom& g);    // bytes of one cached transform of this layer's filter (0: not a Winograd layer)
+// Round 5.  `variant` of a lookup = (0 forward | 1 input gradient | 2 / 3 the same for merged sub-pixel phase filters) | layout << 4: an
+// entry is keyed by (filter, variant & 15) and remembers the layout it was filled in (pipeline fp32 / MFMA-fragment order / bf16 planes);
+// a lookup asking for another layout gets nullptr.  conv_wino_u_variant / conv_up5_wino_u_variant: the lookup a layer's forward
+// (dgrad 0; keepV: the caller keeps the input transform) / input gradient will make (-1: none); conv_wino_prefill: the transforms of
+// `count` equally shaped 3x3 filters w_stride floats apart into U0 + i * u_stride floats, in that layout, as ONE launch.
+int conv_wino_u_variant(const ConvGeom& g, int dgrad, bool keepV);
+int conv_up5_wino_u_variant(const ConvGeom& g, int dgrad, bool keepV);
+int conv_wino_prefill(const ConvGeom& g, int uv, const float* w0, int64_t w_stride, float* U0, int64_t u_stride, int count, hipStream_t st);
+int wino_fused_filter_batch(const float* w0, int64_t w_stride, float* Uf0, int64_t u_stride, int count, int Co, int Ci, int flip, hipStream_t st);
 
 // Winograd F(4x4,3x3) path of the 3x3 stride-1 reflect-pad-1 layers (conv_wino.hip); EUNSUPPORTED when not eligible / no scratch
 bool conv_wino_ok(const ConvGeom& g);
@@ -186,9 +210,13 @@ struct NormST { int x = 0, y = 0, res = 0, dy = 0, dx = 0, dres = 0; };
 int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float* w, const float* b, int w_stride,
              const void* residual, void* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats = nullptr,
              int stats_chunk = 0, const NormST* sto = nullptr);
+// sbc_out (optional, LayerNorm only, [B][C][2] floats): receives the per-sample totals (sum g, sum g*xhat) per channel INSTEAD of the
+// gamma / beta gradients being added here -- the caller adds them later with norm_bwd_ln_params (on its parameter-gradient stream)
 int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy,
              const float* w, int w_stride, const float* mean, const float* rstd, void* dx, float* dw, float* db,
-             void* dres, int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto = nullptr);
+             void* dres, int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto = nullptr, float* sbc_out = nullptr);
+// dgamma[c] += sum_b sbc[b][c][1], dbeta[c] += sum_b sbc[b][c][0], samples added in index order
+int norm_bwd_ln_params(const float* sbc, int B, int C, float* dgamma, float* dbeta, hipStream_t st);
 
 // dy *= act'(y) (y, dy may be stored in different dtypes; n % 4 == 0 unless both are fp32)
 int act_bwd_inplace(int act, const void* y, void* dy, int64_t n, hipStream_t st, int yst = 0, int gst = 0);
@@ -206,6 +234,9 @@ int linear_fwd(int B, int I, int O, const float* x, const float* w, const float*
 // dy is modified in place by the activation backward; dx overwritten (may be null); dw,db accumulate
 int linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, const float* w, int act,
                float* dx, float* dw, float* db, hipStream_t st);
+// the parameter half alone: dw[o][i] += sum_b dy[b][o] x[b][i], db[o] += sum_b dy[b][o]; dy = the gradient AFTER the activation backward
+// (linear_bwd with dw = db = nullptr has applied it)
+int linear_bwd_params(int B, int I, int O, const float* x, const float* dy, float* dw, float* db, hipStream_t st);
 // global average pool NHWC [B][HW][C] (storage xst) -> [B][C] fp32; backward writes dx in storage xst
 int gap_fwd(int B, int HW, int C, const void* x, float* y, hipStream_t st, int xst = 0);
 int gap_bwd(int B, int HW, int C, const float* dy, void* dx, int accumulate, hipStream_t st, int xst = 0);
@@ -229,6 +260,11 @@ int focus_translation_nchw(const float* fg, int64_t fg_bstride, const float* bg,
 // LSGAN (networks.py:67,83,98): loss_slot += weight*mean((o-t)^2); d_o = weight*2(o-t)/n*gscale (if d_o != null)
 // lscale (optional, device): fp16 dynamic loss scale; the gradient seed is multiplied by lscale[0], the reported loss is not
 int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st, const float* lscale = nullptr);
+// the same for up to LSGAN_MAX_TERMS (map, target) terms in ONE launch: the terms are processed in index order by one workgroup, so
+// every slot receives its additions in the order -- and with the values -- of the equivalent sequence of lsgan_loss calls
+struct LsganTerm { const float* o; float* d_o; float* slot; int n; float target, weight, gscale; };
+const int LSGAN_MAX_TERMS = 12;
+int lsgan_loss_batch(const LsganTerm* terms, int nterms, hipStream_t st, const float* lscale = nullptr);
 // L1 (trainer.py:61-62): loss_slot = mean|a[..,:3] - b|; a has a_stride channels (4: decoder output), b 3 channels.
 const int L1_PART_FLOATS = 1024;
 int l1_loss(const float* a, int a_stride, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale, int d_accumulate, hipStream_t st,

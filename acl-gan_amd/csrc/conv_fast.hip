@@ -954,7 +954,7 @@ size_t wgrad_fast_det_bytes(const ConvGeom& g, int Kn, int P, int ny) {
 template <int WM, int WN, int TM, int TN>
 int up5_fwd_t(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, float* wp, hipStream_t st, float* keepV) {
     const int64_t nm = (int64_t)4 * g.Co * 9 * (g.Ci / 4);
-    if (!(conv_up5_wino_ok(g) && wino_u_cached(w, 2))) {      // (the Winograd phases read only the cached transform of the merged filters)
+    if (!(conv_up5_wino_ok(g) && wino_u_cached(w, conv_up5_wino_u_variant(g, 0, keepV != nullptr)))) {      // (the Winograd phases read only the cached transform of the merged filters)
         hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
         ACL_CHECK_LAUNCH("up5_merge_kernel");
     }
@@ -1016,7 +1016,7 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
 template <int WM, int WN, int TM, int TN>
 int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, float* wp, hipStream_t st) {
     const int64_t nm = (int64_t)4 * g.Co * 9 * (g.Ci / 4);
-    if (!(conv_up5_wino_ok(g) && wino_u_cached(w, 3))) {
+    if (!(conv_up5_wino_ok(g) && wino_u_cached(w, conv_up5_wino_u_variant(g, 1, false)))) {
         hipLaunchKernelGGL(up5_merge_kernel, dim3((int)std::min<int64_t>(cdiv64(nm, 256), 2048)), dim3(256), 0, st, w, wp, g.Co, g.Ci);
         ACL_CHECK_LAUNCH("up5_merge_kernel");
     }

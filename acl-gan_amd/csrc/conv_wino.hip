@@ -48,6 +48,11 @@ float* cached_u(float* scratch_u, const float* key, int variant, size_t bytes, b
     if (!u) { *fresh = true; return scratch_u; }
     return u;
 }
+// Layouts a cached transform can have (bits 4.. of the cache lookup's `variant`): the engine keys an entry by (filter, variant & 15) and
+// remembers the layout it was filled in; a lookup that asks for another layout (the tuning switches changed in the middle of an update)
+// gets no cache entry and computes into its own scratch instead of reading a transform in the wrong order.
+enum { U_PIPE = 0, U_FRAG = 1, U_X3 = 2 };
+inline int uvar(int variant, int layout) { return variant | (layout << 4); }
 
 __device__ __forceinline__ int reflw(int v, int n) {
     v = v < 0 ? -v : v;
@@ -101,14 +106,18 @@ __device__ __forceinline__ void at4(const F (&m)[6], F (&y)[4]) {
 // U[f][row][k]: forward: row = cout, k = cin from w[cout][ky][kx][cin];
 // dgrad (flip = 1): row = cin, k = cout from the flipped filter w[cout][2-ky][2-kx][cin]
 // planes > 0 (elements per plane): U is written as the three bf16 planes of the split-bf16 GEMM (gemm_bf16x3.hip) instead of fp32
-__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int flip, int64_t planes) {
+// blockIdx.y = filter of a batch: filter y is read at w + y * wstr and written at U + y * ustr floats (planes: U16 + y * ustr16 halfs) -- the
+// merged phase filters of a sub-pixel layer (wstr = Co * 9 * Ci, back to back) or equally shaped filters of one network (round 5: all ResBlock
+// filters of an encoder / decoder in one launch, wstr = their distance in the flat parameter buffer)
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int flip, int64_t planes,
+                                                          int64_t wstr, int64_t ustr, int64_t ustr16) {
     // one thread = one (row, k) pair of the OUTPUT layout, k fastest: forward (row = cout, k = cin) reads w coalesced along cin;
     // dgrad (row = cin, k = cout, flipped taps) reads w with stride 9*Cin -- 9 strided loads per thread against 36 coalesced stores
     const int R = flip ? Ci : Co, K = flip ? Co : Ci;
     const int64_t n = (int64_t)R * K;
-    w += (size_t)blockIdx.y * Co * 9 * Ci;        // blockIdx.y = phase (merged filters of the sub-pixel layers), else 0
-    unsigned short* U16 = reinterpret_cast<unsigned short*>(U) + (size_t)blockIdx.y * 36 * n;
-    U += (size_t)blockIdx.y * 36 * n;
+    w += (size_t)blockIdx.y * wstr;
+    unsigned short* U16 = reinterpret_cast<unsigned short*>(U) + (size_t)blockIdx.y * ustr16;
+    U += (size_t)blockIdx.y * ustr;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int kk = (int)(i % K), row = (int)(i / K);
         const int co = flip ? kk : row, ci = flip ? row : kk;
@@ -567,7 +576,7 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
     char* cur = (char*)scratch;
     if (!keepV && wino_fused_ok(B, H, W, Cin_, Cout_, act)) {      // one launch (conv_wino_fused.hip): neither V nor M exists in memory
         bool fresh_f = true;
-        float* Uf = cached_u((float*)scratch, w, flip ? 1 : 0, (size_t)36 * Cout_ * Cin_ * 4, &fresh_f);
+        float* Uf = cached_u((float*)scratch, w, uvar(flip ? 1 : 0, U_FRAG), (size_t)36 * Cout_ * Cin_ * 4, &fresh_f);
         if (fresh_f) { const int rcf = wino_fused_filter(w, Uf, w_co, w_ci, flip, st); if (rcf) return rcf; }
         return wino_fused_launch(B, H, W, Cin_, Cout_, in, Uf, bias, out, act, accumulate, reflect, stats, st);
     }
@@ -580,9 +589,10 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
     const WViews vw = one_view(ident_view(H, W));
     const int64_t uplanes = x3 ? (int64_t)36 * Cout_ * Cin_ : 0, vplanes = x3 ? (int64_t)36 * T * Cin_ : 0;
     bool fresh = true;
-    U = cached_u(U, w, flip ? 1 : 0, (size_t)36 * Cout_ * Cin_ * eb, &fresh);
+    U = cached_u(U, w, uvar(flip ? 1 : 0, x3 ? U_X3 : U_PIPE), (size_t)36 * Cout_ * Cin_ * eb, &fresh);
     if (fresh) {
-        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip, uplanes);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)w_co * w_ci, 4096), 1), dim3(256), 0, st, w, U, w_co, w_ci, flip, uplanes,
+                           (int64_t)0, (int64_t)0, (int64_t)0);
         ACL_CHECK_LAUNCH("wino_filter_kernel");
     }
     int rc = launch_wino_input(in, V, B, vw, 1, Cin_, TY, TX, -1, reflect, st, vplanes);
@@ -592,6 +602,29 @@ int wino_run(int B, int H, int W, int Cin_, int Cout_, const float* in, const fl
     return launch_wino_output(M, bias, out, B, vw, Cout_, TY, TX, act, accumulate, 0, st, stats);
 }
 }  // namespace
+// Which cache entry (variant | layout << 4) the forward (dgrad = 0; keepV: the caller keeps the input transform) / the input gradient
+// (dgrad = 1) of this 3x3 layer will ask for -- the same decisions as wino_run, for the scheduler's batched prefill.  -1: not a Winograd layer.
+int conv_wino_u_variant(const ConvGeom& g, int dgrad, bool keepV) {
+    if (!conv_wino_ok(g)) return -1;
+    const int Cin_ = dgrad ? g.Co : g.Ci, Cout_ = dgrad ? g.Ci : g.Co, act = dgrad ? ACLGAN_ACT_NONE : g.act;
+    const int64_t T = (int64_t)g.B * (g.Hi / 4) * (g.Wi / 4);
+    if (dgrad) keepV = false;
+    if (!keepV && wino_fused_ok(g.B, g.Hi, g.Wi, Cin_, Cout_, act)) return uvar(dgrad, U_FRAG);
+    const bool x3 = !keepV && wino_x3() && gemm_x3_shape_ok((int)T, Cin_, Cout_);
+    return uvar(dgrad, x3 ? U_X3 : U_PIPE);
+}
+// The transforms of `count` equally shaped 3x3 filters (w0 + i * w_stride floats, OHWI) into U0 + i * u_stride floats, in the layout of
+// cache entry `uv`: ONE launch (the ~100 per-filter launches of a step were pure dispatch latency: 6 - 16 us each for 2.4 MB of output)
+int conv_wino_prefill(const ConvGeom& g, int uv, const float* w0, int64_t w_stride, float* U0, int64_t u_stride, int count, hipStream_t st) {
+    if (!conv_wino_ok(g) || uv < 0 || count < 1) return ACLGAN_EUNSUPPORTED;
+    const int flip = uv & 1, layout = uv >> 4;
+    if (layout == U_FRAG) return wino_fused_filter_batch(w0, w_stride, U0, u_stride, count, g.Co, g.Ci, flip, st);
+    const int64_t planes = layout == U_X3 ? (int64_t)36 * g.Co * g.Ci : 0;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), count), dim3(256), 0, st, w0, U0, g.Co, g.Ci, flip, planes,
+                       w_stride, u_stride, u_stride * 2);
+    ACL_CHECK_LAUNCH("wino_filter_kernel(batch)");
+    return ACLGAN_OK;
+}
 // stats (optional): [B][Ho/4 * Wo/4][Co] (mean, M2) pairs of the 4x4 output tiles -- the normalisation layer's chunk partials, for free
 // keepV (optional, conv_wino_keep_bytes(g) bytes): receives V = B^T x B -- conv_wgrad_wino(.., haveV) of the same layer skips its
 // input transform
@@ -675,6 +708,17 @@ Up5Geo up5_geo(const ConvGeom& g) {
 }
 }  // namespace
 // forward: U [4][36][Co][Ci] | V [36][T][Ci] | M [4][36][T][Co]
+// ... and of the merged phase filters of a sub-pixel layer (what conv_up5_wino_fwd_phases / _dgrad_phases will ask for)
+int conv_up5_wino_u_variant(const ConvGeom& g, int dgrad, bool keepV) {
+    if (!conv_up5_wino_ok(g)) return -1;
+    const Up5Geo q = up5_geo(g);
+    if (!dgrad) {
+        if (!keepV && wino_fused_ok(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, g.act, 4, 1)) return uvar(2, U_FRAG);
+        return uvar(2, (!keepV && wino_x3() && gemm_x3_shape_ok((int)q.T, g.Ci, g.Co)) ? U_X3 : U_PIPE);
+    }
+    if (wino_fused_ok(g.B, g.Hi, g.Wi, g.Co, g.Ci, ACLGAN_ACT_NONE, 1, 4)) return uvar(3, U_FRAG);
+    return uvar(3, (wino_x3() && gemm_x3_shape_ok((int)q.Td, g.Co, g.Ci)) ? U_X3 : U_PIPE);
+}
 size_t conv_up5_wino_fwd_scratch_bytes(const ConvGeom& g) {
     if (!conv_up5_wino_ok(g)) return 0;
     const Up5Geo q = up5_geo(g);
@@ -693,7 +737,7 @@ int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp,
     char* cur = (char*)scratch;
     if (!keepV && wino_fused_ok(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, g.act, 4, 1)) {      // the four phases in one fused launch (conv_wino_fused.hip)
         bool fresh_f = true;
-        float* Uf = cached_u((float*)scratch, wkey, 2, (size_t)144 * g.Co * g.Ci * 4, &fresh_f);
+        float* Uf = cached_u((float*)scratch, wkey, uvar(2, U_FRAG), (size_t)144 * g.Co * g.Ci * 4, &fresh_f);
         if (fresh_f) { const int rcf = wino_fused_filter(wp, Uf, g.Co, g.Ci, 0, st, 4); if (rcf) return rcf; }
         return wino_fused_up5_fwd(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, Uf, bias, y, g.Ho, g.Wo, g.act, st);
     }
@@ -705,9 +749,10 @@ int conv_up5_wino_fwd_phases(const ConvGeom& g, const float* x, const float* wp,
     if (keepV) V = keepV;
     const int64_t uplanes = x3 ? (int64_t)144 * g.Co * g.Ci : 0, vplanes = x3 ? (int64_t)36 * q.T * g.Ci : 0;
     bool fresh = true;
-    U = cached_u(U, wkey, 2, (size_t)144 * g.Co * g.Ci * eb, &fresh);
+    U = cached_u(U, wkey, uvar(2, x3 ? U_X3 : U_PIPE), (size_t)144 * g.Co * g.Ci * eb, &fresh);
     if (fresh) {
-        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0, uplanes);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 0, uplanes,
+                           (int64_t)g.Co * 9 * g.Ci, (int64_t)36 * g.Co * g.Ci, (int64_t)36 * g.Co * g.Ci);
         ACL_CHECK_LAUNCH("wino_filter_kernel(up5)");
     }
     int rc = launch_wino_input(x, V, g.B, one_view(ident_view(g.Hi, g.Wi)), 1, g.Ci, q.TY, q.TX, 0, 0, st, vplanes);
@@ -729,7 +774,7 @@ int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* 
     char* cur = (char*)scratch;
     if (wino_fused_ok(g.B, g.Hi, g.Wi, g.Co, g.Ci, ACLGAN_ACT_NONE, 1, 4)) {      // one fused launch: K loop over (phase, cout)
         bool fresh_f = true;
-        float* Uf = cached_u((float*)scratch, wkey, 3, (size_t)144 * g.Co * g.Ci * 4, &fresh_f);
+        float* Uf = cached_u((float*)scratch, wkey, uvar(3, U_FRAG), (size_t)144 * g.Co * g.Ci * 4, &fresh_f);
         if (fresh_f) { const int rcf = wino_fused_filter(wp, Uf, g.Co, g.Ci, 1, st, 4); if (rcf) return rcf; }
         return wino_fused_up5_dgrad(g.B, g.Hi, g.Wi, g.Ci, g.Co, dy, Uf, dx, g.Ho, g.Wo, accumulate, st);
     }
@@ -740,9 +785,10 @@ int conv_up5_wino_dgrad_phases(const ConvGeom& g, const float* dy, const float* 
     float* M = take(cur, (size_t)144 * q.Td * g.Ci * 4);
     const int64_t uplanes = x3 ? (int64_t)144 * g.Co * g.Ci : 0, vplanes = x3 ? (int64_t)144 * q.Td * g.Co : 0;
     bool fresh = true;
-    U = cached_u(U, wkey, 3, (size_t)144 * g.Co * g.Ci * eb, &fresh);
+    U = cached_u(U, wkey, uvar(3, x3 ? U_X3 : U_PIPE), (size_t)144 * g.Co * g.Ci * eb, &fresh);
     if (fresh) {
-        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1, uplanes);
+        hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, wp, U, g.Co, g.Ci, 1, uplanes,
+                           (int64_t)g.Co * 9 * g.Ci, (int64_t)36 * g.Co * g.Ci, (int64_t)36 * g.Co * g.Ci);
         ACL_CHECK_LAUNCH("wino_filter_kernel(up5 dgrad)");
     }
     // dx[u] = sum_k wflip[k] dy_phase[u - 2 + k]: patches start 2 before the tile, zero outside the 62 x 62 phase view

@@ -92,11 +92,14 @@ __device__ __forceinline__ void g6f(const float (&g)[3], float (&u)[6]) {
 // U in fragment order: Uf[cb][kq][wave g][fi][lane][j][e]  (floats): a lane's two 32-channel halves j of one frequency are ONE 16-byte load
 //   row R (forward: cout, dgrad: cin) = cb * 64 + j * 32 + (lane & 31);  k (forward: cin, dgrad: cout) = kq * 4 + 2 * (lane >> 5) + e
 //   frequency (i, jf): wave g = (i / 3) * 2 + jf / 3, fi = (i % 3) * 3 + jf % 3
-__global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __restrict__ w, float* __restrict__ Uf, int Co, int Ci, int flip) {
+// blockIdx.y = filter of a batch (w + y * wstr -> Uf + y * ustr floats): the merged phase filters of a sub-pixel layer, or -- round 5 -- all
+// equally shaped ResBlock filters of an encoder / decoder (wstr = their distance in the flat parameter buffer)
+__global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __restrict__ w, float* __restrict__ Uf, int Co, int Ci, int flip,
+                                                               int64_t wstr, int64_t ustr) {
     const int R = flip ? Ci : Co, K = flip ? Co : Ci, KQ = K >> 2;
     const int64_t n = (int64_t)R * K;
-    w += (size_t)blockIdx.y * Co * 9 * Ci;            // blockIdx.y = phase (merged filters of the sub-pixel layers), else 0
-    Uf += (size_t)blockIdx.y * 36 * n;
+    w += (size_t)blockIdx.y * wstr;
+    Uf += (size_t)blockIdx.y * ustr;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
         // consecutive threads -> consecutive rows of one k (the 36 stores of a wave then fill 128-byte runs of the fragment layout)
         const int row = (int)(idx % R), kk = (int)(idx / R);
@@ -495,8 +498,17 @@ size_t wino_fused_u_bytes(int Cin_, int Cout_) { return (size_t)36 * Cin_ * Cout
 // Uf <- fragment-ordered G g G^T of w (flip: the flipped, transposed filter of the input gradient); nph filters back to back
 int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st, int nph) {
     const int64_t n = (int64_t)Co * Ci;
-    hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096), nph), dim3(256), 0, st, w, Uf, Co, Ci, flip);
+    hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096), nph), dim3(256), 0, st, w, Uf, Co, Ci, flip,
+                       (int64_t)Co * 9 * Ci, (int64_t)36 * n);
     ACL_CHECK_LAUNCH("wino_filter_frag_kernel");
+    return ACLGAN_OK;
+}
+// `count` equally shaped filters, w_stride floats apart, into Uf0 + i * u_stride floats: one launch
+int wino_fused_filter_batch(const float* w0, int64_t w_stride, float* Uf0, int64_t u_stride, int count, int Co, int Ci, int flip, hipStream_t st) {
+    const int64_t n = (int64_t)Co * Ci;
+    hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 1024), count), dim3(256), 0, st, w0, Uf0, Co, Ci, flip,
+                       w_stride, u_stride);
+    ACL_CHECK_LAUNCH("wino_filter_frag_kernel(batch)");
     return ACLGAN_OK;
 }
 

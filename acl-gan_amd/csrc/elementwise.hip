@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restr
 
 int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy, const float* w,
              int w_stride, const float* mean, const float* rstd, void* dx, float* dw, float* db, void* dres,
-             int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto) {
+             int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto, float* sbc_out) {
     const NormST sd = sto ? *sto : NormST();
     ACL_REQUIRE(pow2(C) && C >= 4 && C <= 1024, "norm: C=%d must be a power of two in [4,1024]", C);
     const int chunk = norm_chunk_pixels(B, HW), nchunks = cdiv(HW, chunk);
@@ -464,10 +464,10 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
     ACL_CHECK_LAUNCH("norm_bwd_reduce_kernel");
     if (kind == ACLGAN_NORM_LN) {
         ACL_REQUIRE(w, "LN backward needs gamma");
-        float* sbc = cC + (size_t)B * C;   // [B][C][2] totals (scratch tail, see norm_scratch_bytes)
+        float* sbc = sbc_out ? sbc_out : cC + (size_t)B * C;   // [B][C][2] totals (scratch tail, see norm_scratch_bytes; or the caller's buffer)
         hipLaunchKernelGGL(norm_bwd_finalize_ln_kernel, dim3(B), dim3(256), 0, st, part, B, C, HW, nchunks, w, rstd, cA, cB, cC, dw, db, sbc);
         ACL_CHECK_LAUNCH("norm_bwd_finalize_ln_kernel");
-        if (dw || db) {
+        if ((dw || db) && !sbc_out) {
             hipLaunchKernelGGL(norm_bwd_ln_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sbc, B, C, dw, db);
             ACL_CHECK_LAUNCH("norm_bwd_ln_params_kernel");
         }
@@ -482,6 +482,13 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, cA, cB, cC, dx, dres, dres_accumulate,
                        HW, C, act, total4);
     ACL_CHECK_LAUNCH("norm_bwd_apply_kernel");
+    return ACLGAN_OK;
+}
+
+int norm_bwd_ln_params(const float* sbc, int B, int C, float* dgamma, float* dbeta, hipStream_t st) {
+    if (!dgamma && !dbeta) return ACLGAN_OK;
+    hipLaunchKernelGGL(norm_bwd_ln_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sbc, B, C, dgamma, dbeta);
+    ACL_CHECK_LAUNCH("norm_bwd_ln_params_kernel");
     return ACLGAN_OK;
 }
 

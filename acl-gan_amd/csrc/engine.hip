@@ -23,6 +23,8 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <tuple>
+#include <algorithm>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -55,6 +57,12 @@ struct Act {
     bool need_grad = false;
     bool gw = false;   // gradient buffer holds valid data (first writer overwrites, later ones accumulate)
     Act* parent = nullptr;   // batch-slice view of a joint tensor: its gradient arrives through the parent
+    // lane stamps (aclgan_ctx lanes): which lane last wrote d / touched g, and the index of that lane's checkpoint that covers the
+    // write.  Views stamp their joint tensor (the halves of a joint discriminator batch are written on different lanes).
+    struct Stamp { int lane, ck; };
+    Stamp dst[4]; int ndst = 0;
+    Stamp gst = {-1, 0};
+    Act* root() { return parent ? parent : this; }
     int64_t numel() const { return (int64_t)B * H * W * C; }
     bool written() const { return gw || (parent && parent->gw); }
 };
@@ -72,6 +80,8 @@ struct TapeOp {
     std::function<int()> fn;
     int64_t goff[4] = {0, 0, 0, 0}, gnum[4] = {0, 0, 0, 0};
     int ng = 0;
+    int lane = 0;      // the lane (stream) its kernels are enqueued on = the lane of the forward pass that pushed it
+    int pass = -1;     // forward pass it belongs to: a lane checkpoint is taken whenever the replay moves to another pass
 };
 
 }  // namespace aclgan
@@ -117,13 +127,13 @@ struct aclgan_ctx {
         cur_pass = (int)pass_names.size() - 1;
         // "@N": the library's launch counter when the range opens -- kernels are asynchronous, so a trace is cut by launch ORDER, not by
         // host time (scripts/rocpd_bypass.py): the range owns the library launches N .. (N of its "~end" marker) - 1
-        Roctx::get().push((pass_names.back() + "@" + std::to_string(g_launches)).c_str());
+        Roctx::get().push((pass_names.back() + "@" + std::to_string((long long)g_launches)).c_str());
         return prev;
     }
     void pass_end(int prev) {
         if (!Roctx::get().on || dry) return;
         Roctx::get().pop();
-        Roctx::get().push(("~end@" + std::to_string(g_launches)).c_str());
+        Roctx::get().push(("~end@" + std::to_string((long long)g_launches)).c_str());
         Roctx::get().pop();
         cur_pass = prev;
     }
@@ -153,6 +163,14 @@ struct aclgan_ctx {
     aclgan_bucket_fn bucket_fn = nullptr;
     void* bucket_user = nullptr;
     std::vector<int> bucket_order;   // buckets in the order they completed during the last update
+    // workspace need of an update by (update, shape, dtype, switch setting): step_common checks the bound workspace against it
+    struct NeedKey {
+        int which, B, H, W, dtype; long long epoch; int determ, buckets;
+        bool operator<(const NeedKey& o) const {
+            return std::tie(which, B, H, W, dtype, epoch, determ, buckets) < std::tie(o.which, o.B, o.H, o.W, o.dtype, o.epoch, o.determ, o.buckets);
+        }
+    };
+    std::map<NeedKey, size_t> need_cache;
     // ALGORITHMIC HBM bytes of the step being built (aclgan_step_algorithmic_bytes): every operator's inputs read once and
     // outputs written once at their storage width -- what a perfectly fused-per-operator implementation must move
     double alg_bytes = 0.0;
@@ -160,24 +178,35 @@ struct aclgan_ctx {
     size_t keep_total = 0;      // bytes of Winograd input transforms kept for the weight gradients of this update (conv_block)
     // Winograd filter transforms of this update, by (filter tensor, variant): computed by the first layer call that needs one, reused by
     // the later calls of the same network (common.h: WinoUCache); the buffers live in the arena until the update ends
-    struct UEnt { float* u; bool filled; };
+    struct UEnt { float* u; bool filled; int layout; int lane, ck; };
     std::map<std::pair<const float*, int>, UEnt> ucache;
     WinoUCache ucache_hook;
     static bool ucache_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ACLGAN_NOUCACHE"); v = (e && atoi(e)) ? 0 : 1; } return v == 1; }
+    // variant = (0 forward | 1 input gradient | 2 / 3 merged sub-pixel phase filters) | layout << 4 (conv_wino.hip).  An entry remembers the
+    // layout it was filled in and the lane that filled it: another layout gets no entry (the caller computes into its scratch -- never a
+    // transform read in the wrong order), another lane waits for the filling lane's checkpoint.
     static float* ucache_lookup(void* user, const float* w, int variant, size_t bytes, bool* fresh) {
         aclgan_ctx* c = (aclgan_ctx*)user;
-        auto it = c->ucache.find(std::make_pair(w, variant));
+        const int layout = variant >> 4;
+        auto it = c->ucache.find(std::make_pair(w, variant & 15));
         if (it == c->ucache.end()) return nullptr;       // not reserved (operator-level call paths): the caller uses its scratch slice
-        *fresh = !it->second.filled;
-        if (bytes) it->second.filled = true;             // (bytes == 0: a peek)
-        return it->second.u;
+        UEnt& e = it->second;
+        if (!e.filled) {
+            *fresh = true;
+            if (bytes) { e.filled = true; e.layout = layout; e.lane = c->cur_lane; e.ck = c->nck(c->cur_lane); }      // (bytes == 0: a peek)
+            return e.u;
+        }
+        if (e.layout != layout) return nullptr;
+        *fresh = false;
+        if (bytes && c->nlanes > 1 && e.lane != c->cur_lane) (void)c->wait_ck(c->cur_lane, e.lane, e.ck);
+        return e.u;
     }
     // make sure the arena holds a slot for the transform of (w, variant); call where an allocation may persist until the update ends
     int ucache_reserve(const float* w, int variant, size_t bytes) {
         if (!ucache_enabled() || !bytes || ucache.count(std::make_pair(w, variant))) return ACLGAN_OK;
         float* u = (float*)alloc(bytes);
         if (!u) return ACLGAN_ENOMEM;
-        ucache[std::make_pair(w, variant)] = UEnt{u, false};
+        ucache[std::make_pair(w, variant)] = UEnt{u, false, 0, 0, 0};
         return ACLGAN_OK;
     }
     // 16-bit activation / gradient storage of the wide layers (C % 64 == 0) under a 16-bit compute dtype; co16: also the conv outputs
@@ -190,9 +219,12 @@ struct aclgan_ctx {
     // ends (x, dy, the kept Winograd transform) and nothing in the backward waits for it, while the input gradient is on the critical
     // path -- so the weight-gradient pipeline of layer L (transforms: HBM-bound, GEMM: MFMA-bound, finishes: latency-bound) runs on a
     // second stream next to the input-gradient pipeline of L and the norm backward of L-1, filling each other's tails and dispatch
-    // gaps.  Fork = an event on the main stream after dy is complete; join = before a gradient bucket is handed to the all-reduce and
-    // at the end of the tape.  Its scratch is a second stack growing down from the END of the workspace (stream-ordered reuse).
+    // gaps.  Fork = an event on the closure's stream after dy is complete; join = before a gradient bucket is handed to the all-reduce
+    // and at the end of the tape.  Its scratch is a second stack growing down from the END of the workspace (stream-ordered reuse).
     // ACLGAN_SIDE_STREAM=0 turns it off (everything on the caller's stream, as in round 2).
+    // Round 5: it is THE parameter-gradient stream -- every kernel that accumulates into the trained group's flat gradient buffer
+    // (convolution weight / bias gradients, LayerNorm gamma / beta, the dense layers' dw / db) runs on it, in tape order, whatever lane
+    // the rest of its closure runs on: two lanes never add into the same parameter gradient concurrently, the sums keep one fixed order.
     hipStream_t st2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;
@@ -203,10 +235,12 @@ struct aclgan_ctx {
         top2 = need;
         if (need > peak2) peak2 = need;
         if (dry) return (void*)(uintptr_t)4096;
-        if (top + need > ws_bytes) return nullptr;
+        // the main stack's high-water mark of this step, not its current top: scratch the host has released may still be in use by
+        // kernels in flight on a lane
+        if (peak + need + 256 > ws_bytes) return nullptr;
         return ws + ((ws_bytes - need) & ~(size_t)255);
     }
-    int side_fork() {       // the side stream may start once everything enqueued on the main stream so far is done
+    int side_fork() {       // the side stream may start once everything enqueued on the current lane so far is done
         if (dry) return ACLGAN_OK;
         if (!st2) {
             // ACLGAN_SIDE_PRIO=1: the side stream at the highest priority the device offers (its kernels are small and fill the tails of the
@@ -227,19 +261,156 @@ struct aclgan_ctx {
         side_pending = true;
         return ACLGAN_OK;
     }
-    int side_join() {       // the main stream waits for everything the side stream was given
+    int side_join() {       // lane 0 (the caller's stream) waits for everything the side stream was given
         if (dry || !side_pending) return ACLGAN_OK;
         hipError_t e = hipEventRecord(ev_join, st2);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st0 ? st0 : st, ev_join, 0);
         if (e != hipSuccess) return aclgan::hip_fail(e, "side stream join");
         side_pending = false;
         return ACLGAN_OK;
+    }
+
+    // ---- Lanes (round 5): independent branches of the step on separate HIP streams.
+    // The reference's step is a graph with wide independent branches -- the two translation directions (trainer.py:103-116), the
+    // reconstruction decodes (trainer.py:113-114), three discriminators with three scales each (trainer.py:136-139, networks.py:50-57) --
+    // which a single in-order queue serialises, so that every launch that does not fill the chip (late discriminator layers, style
+    // encoder tails, split-K finishes, statistics finalizes, MLP layers) costs its full latency.  A lane is a stream; lane 0 is the
+    // caller's.  The update functions assign every network pass to a lane (set_lane), every backward closure runs on the lane of the
+    // pass that recorded it, and the host still builds / replays everything in ONE fixed order, so the accumulate-or-overwrite flags,
+    // the order of every sum and the bucket schedule are exactly those of the single-queue plan: results do not depend on the number
+    // of lanes (tests/test_gpu_determinism.py compares them bitwise).
+    //   Dependencies: a lane takes a CHECKPOINT (an event) whenever the host leaves it and at every pass boundary; an activation
+    //   carries a stamp (lane, checkpoint index) per writer of its data and one for the last toucher of its gradient; a consumer on
+    //   another lane waits for exactly that checkpoint (need / acq).  Parameter gradients never cross lanes: they live on the side stream.
+    //   Memory: the arena stays one stack.  Scratch released by the host may still be in use on its lane, so an allocation made on
+    //   lane L starts above the high-water mark of every OTHER lane (hw); same-lane reuse is stream-ordered as before.  The marks
+    //   reset where all lanes meet (lanes_barrier).  The dry run follows the same rule, so aclgan_workspace_bytes stays exact.
+    static const int MAXL = 4;
+    hipStream_t st0 = nullptr;                       // the caller's stream = lane 0 (st = the current lane's stream)
+    hipStream_t lane_st[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    int nlanes = 1, cur_lane = 0;
+    std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
+    std::vector<hipEvent_t> lane_evs[MAXL];          // lane_evs[l][k]: the k-th checkpoint of lane l in this step
+    int seen[MAXL][MAXL] = {};                       // seen[d][s]: lane d has waited for the first seen[d][s] checkpoints of lane s
+    size_t hw[MAXL] = {0, 0, 0, 0};
+    int pass_seq = 0, cur_pass_id = -1;              // forward pass ids (always on; the roctx labels are separate)
+    hipStream_t lane_stream(int l) const { return l == 0 ? st0 : lane_st[l]; }
+    int nck(int l) const { return (int)lane_evs[l].size(); }
+    // lanes of this step; streams are created on first use and live as long as the context
+    int lanes_begin(int want) {
+        nlanes = std::max(1, std::min(want, (int)MAXL));
+        if (!side_enabled()) nlanes = 1;             // parameter gradients need their own ordered stream once there is more than one lane
+        cur_lane = 0; st0 = st;
+        for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
+        ev_next = 0;
+        if (dry) return ACLGAN_OK;
+        for (int l = 1; l < nlanes; ++l)
+            if (!lane_st[l]) { hipError_t e = hipStreamCreateWithFlags(&lane_st[l], hipStreamNonBlocking); if (e != hipSuccess) return aclgan::hip_fail(e, "lane stream"); }
+        return ACLGAN_OK;
+    }
+    // checkpoint of lane l: everything enqueued on it so far
+    int checkpoint(int l) {
+        hipEvent_t ev = nullptr;
+        if (!dry) {
+            if (ev_next == ev_pool.size()) {
+                hipEvent_t e = nullptr;
+                hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                if (rc != hipSuccess) return aclgan::hip_fail(rc, "lane event");
+                ev_pool.push_back(e);
+            }
+            ev = ev_pool[ev_next++];
+            hipError_t rc = hipEventRecord(ev, lane_stream(l));
+            if (rc != hipSuccess) return aclgan::hip_fail(rc, "lane checkpoint");
+        }
+        lane_evs[l].push_back(ev);
+        return ACLGAN_OK;
+    }
+    // pass boundary on the current lane (stamps taken before it are covered by this checkpoint)
+    int mark() { return nlanes > 1 ? checkpoint(cur_lane) : ACLGAN_OK; }
+    int set_lane(int l) {
+        if (nlanes <= 1) return ACLGAN_OK;
+        l %= nlanes;
+        if (l == cur_lane) return ACLGAN_OK;
+        int rc = checkpoint(cur_lane);
+        if (rc) return rc;
+        cur_lane = l;
+        if (!dry) st = lane_stream(l);
+        return ACLGAN_OK;
+    }
+    // lane d waits for checkpoint k of lane s
+    int wait_ck(int d, int s, int k) {
+        if (d == s || k < seen[d][s]) return ACLGAN_OK;
+        if (k >= nck(s)) {                            // not checkpointed yet (s is the current lane and d is not: join paths only)
+            int rc = checkpoint(s);
+            if (rc) return rc;
+            k = nck(s) - 1;
+        }
+        if (!dry) {
+            hipError_t e = hipStreamWaitEvent(lane_stream(d), lane_evs[s][k], 0);
+            if (e != hipSuccess) return aclgan::hip_fail(e, "lane wait");
+        }
+        seen[d][s] = k + 1;
+        return ACLGAN_OK;
+    }
+    // the current lane is about to READ a's data
+    int need(Act* a) {
+        if (nlanes <= 1 || !a) return ACLGAN_OK;
+        Act* r = a->root();
+        for (int i = 0; i < r->ndst; ++i)
+            if (r->dst[i].lane != cur_lane) { int rc = wait_ck(cur_lane, r->dst[i].lane, r->dst[i].ck); if (rc) return rc; }
+        return ACLGAN_OK;
+    }
+    // the current lane has enqueued a writer of a's data
+    void wrote(Act* a) {
+        if (!a) return;
+        Act* r = a->root();
+        for (int i = 0; i < r->ndst; ++i)
+            if (r->dst[i].lane == cur_lane) { r->dst[i].ck = nck(cur_lane); return; }
+        if (r->ndst < 4) r->dst[r->ndst++] = Act::Stamp{cur_lane, nck(cur_lane)};
+    }
+    // the current lane is about to read or write a's GRADIENT (backward): order it after the previous toucher
+    int acq(Act* a) {
+        if (nlanes <= 1 || !a) return ACLGAN_OK;
+        Act* r = a->root();
+        if (r->gst.lane >= 0 && r->gst.lane != cur_lane) { int rc = wait_ck(cur_lane, r->gst.lane, r->gst.ck); if (rc) return rc; }
+        r->gst = Act::Stamp{cur_lane, nck(cur_lane)};
+        return ACLGAN_OK;
+    }
+    // lane 0 waits for everything enqueued on every lane and on the side stream; the current lane becomes lane 0
+    int lanes_join() {
+        if (nlanes > 1) {
+            int rc = set_lane(0);
+            if (rc) return rc;
+            for (int l = 1; l < nlanes; ++l)
+                if (nck(l) > 0) { rc = wait_ck(0, l, nck(l) - 1); if (rc) return rc; }
+        }
+        return side_join();
+    }
+    // every lane waits for everything enqueued so far anywhere: scratch of all lanes may be reused from here on
+    int lanes_barrier() {
+        int rc = lanes_join();
+        if (rc || nlanes <= 1) return rc;
+        rc = checkpoint(0);
+        if (rc) return rc;
+        for (int l = 1; l < nlanes; ++l) { rc = wait_ck(l, 0, nck(0) - 1); if (rc) return rc; }
+        for (int l = 0; l < MAXL; ++l) hw[l] = 0;
+        return ACLGAN_OK;
+    }
+    // error paths: nothing of this step may still be in flight on a stream the caller does not know about when control returns
+    void lanes_quiesce() {
+        if (dry) return;
+        for (int l = 1; l < nlanes; ++l) if (lane_st[l]) (void)hipStreamSynchronize(lane_st[l]);
+        if (st2) (void)hipStreamSynchronize(st2);
+        side_pending = false;
+        cur_lane = 0; if (st0) st = st0;
     }
     ~aclgan_ctx() {
         reset_step();
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (st2) (void)hipStreamDestroy(st2);
+        for (int l = 1; l < MAXL; ++l) if (lane_st[l]) (void)hipStreamDestroy(lane_st[l]);
     }
     void reset_step() {
         for (Act* a : acts) delete a;
@@ -250,13 +421,20 @@ struct aclgan_ctx {
         top2 = 0;
         keep_total = 0;
         ucache.clear();
+        for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
+        ev_next = 0; cur_lane = 0; nlanes = 1; pass_seq = 0; cur_pass_id = -1;
+        if (st0) { st = st0; st0 = nullptr; }
     }
     void* alloc(size_t bytes) {
-        const size_t a = (top + 255) & ~(size_t)255;
+        size_t a = (top + 255) & ~(size_t)255;
+        if (nlanes > 1) for (int l = 0; l < nlanes; ++l) if (l != cur_lane && hw[l] > a) a = hw[l];
         top = a + bytes;
+        if (nlanes > 1) { const size_t e = (top + 255) & ~(size_t)255; if (e > hw[cur_lane]) hw[cur_lane] = e; }
         if (top > peak) peak = top;
         if (dry) return (void*)(uintptr_t)(a + 4096);   // fake, never dereferenced
-        if (top > ws_bytes) return nullptr;
+        // the side stream's stack grows down from the end of the workspace and its kernels may still be running: the main stack
+        // must stay below the deepest point that stack has reached in this step (an undersized workspace fails, it does not corrupt)
+        if (top + peak2 + 256 > ws_bytes) return nullptr;
         return ws + a;
     }
     float* allocf(int64_t n) { return (float*)alloc((size_t)n * sizeof(float)); }
@@ -267,6 +445,7 @@ struct aclgan_ctx {
         a->d = (float*)alloc((size_t)a->numel() * (st ? 2 : 4));
         if (need_grad) a->g = allocf(a->numel());
         acts.push_back(a);
+        wrote(a);
         return a;
     }
     // view of `nb` samples starting at sample b0 of a joint activation (no allocation)
@@ -288,6 +467,7 @@ struct aclgan_ctx {
         if (trained >= 0 && groups[trained].grad)
             for (const auto& g : grads)
                 if (g.first && g.second > 0 && op.ng < 4) { op.goff[op.ng] = g.first - groups[trained].grad; op.gnum[op.ng] = g.second; ++op.ng; }
+        op.lane = cur_lane; op.pass = cur_pass_id;
         tape.push_back(std::move(op));
         tape_pass.push_back(cur_pass);
     }
@@ -417,9 +597,9 @@ static size_t keepv_budget() {
 
 // roctx range of one forward pass of a network (ACLGAN_ROCTX=1); closes on every return path
 struct PassScope {
-    aclgan_ctx& c; int prev;
-    PassScope(aclgan_ctx& c_, int net, const char* what) : c(c_), prev(c_.pass_begin(NET_NAMES[net], what)) {}
-    ~PassScope() { c.pass_end(prev); }
+    aclgan_ctx& c; int prev, prev_id;
+    PassScope(aclgan_ctx& c_, int net, const char* what) : c(c_), prev(c_.pass_begin(NET_NAMES[net], what)), prev_id(c_.cur_pass_id) { c.cur_pass_id = c.pass_seq++; }
+    ~PassScope() { c.pass_end(prev); c.cur_pass_id = prev_id; }
 };
 
 struct NormSpec {
@@ -447,6 +627,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     ConvGeom g;
     CHK(make_geom(&d, &g));
     if (!W.w) { set_error("conv_block: parameters not bound"); return ACLGAN_EINVAL; }
+    CHK(c.need(in)); CHK(c.need(residual));      // (another lane may have produced them)
     Act* const gin = in;                          // the tensor this block's input gradient is delivered to
     const bool want_grad = train_w || in->need_grad || ns.dw != nullptr;
     const bool has_norm = ns.kind != ACLGAN_NORM_NONE;
@@ -527,12 +708,16 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     }
     c.top = mark;
     *out_p = out;
+    c.wrote(out); c.wrote(co);
     if (!want_grad) return ACLGAN_OK;
     aclgan_ctx* cp = &c;
     const bool ln_train = ns.kind == ACLGAN_NORM_LN && ns.dw != nullptr;
     c.push([=]() -> int {
         aclgan_ctx& c = *cp;
         if (!out->gw) return ACLGAN_OK;   // no gradient reached this block
+        CHK(c.acq(out));
+        if (residual && residual->need_grad) CHK(c.acq(residual));
+        if (gin->need_grad) CHK(c.acq(gin));
         // backward of norm / activation: x (or y), dy -> dx (+ dres); wgrad: x, dy -> dw, db; dgrad: dy, w -> dx
         const double eg_out = out->gdt ? 2.0 : 4.0, eg_co = (has_norm ? co->gdt : (s_bwd ? dt : out->gdt)) ? 2.0 : 4.0, eg_in = gin->gdt ? 2.0 : 4.0;
         c.count((es_co + eg_out + eg_co) * (double)co->numel() + ((residual && residual->need_grad) ? (residual->gdt ? 2.0 : 4.0) * (double)co->numel() : 0.0));
@@ -546,6 +731,10 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             g16 = (float*)c.alloc((size_t)out->numel() * 2);
             NEED(g16);
         }
+        // LayerNorm gamma / beta gradients are parameter gradients: with the side stream on they are added there (the per-sample
+        // totals sbc [B][C][2] stay put until then: allocated below the closure's scratch mark)
+        float* sbc = nullptr;
+        if (ln_train && side) { sbc = c.allocf((int64_t)2 * g.B * Co); NEED(sbc); }
         const size_t mark0 = side ? c.top : mark_pre;
         const float* dyp = nullptr;       // gradient w.r.t. the conv output, as the dgrad / wgrad kernels read it
         int dy_st = 0;
@@ -557,7 +746,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             if (residual && residual->need_grad) { dres = residual->g; dacc = residual->gw ? 1 : 0; mark_written(residual); }
             NormST bst;
             bst.x = co->dt; bst.y = out->dt; bst.dy = out->gdt; bst.dx = co->gdt; bst.dres = residual ? residual->gdt : 0;
-            RUN(norm_bwd(ns.kind, act, g.B, HW, Co, co->d, out->d, out->g, ns.w, ns.w_stride, mean, rstd, co->g, ns.dw, ns.db, dres, dacc, scr, c.st, &bst));
+            RUN(norm_bwd(ns.kind, act, g.B, HW, Co, co->d, out->d, out->g, ns.w, ns.w_stride, mean, rstd, co->g, ns.dw, ns.db, dres, dacc, scr, c.st, &bst, sbc));
             c.top = mark;
             dyp = co->g; dy_st = co->gdt;
         } else if (s_bwd && out->gdt == 0) {
@@ -579,6 +768,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
                 if (!c.dry) wst = c.st2;
                 c.top2 = 0;                   // side-stream work is stream-ordered: its scratch stack restarts with every launch group
                 if (wb) { wscr = c.alloc2(wb); if (!wscr) { set_error("workspace too small for the side-stream scratch"); return ACLGAN_ENOMEM; } }
+                if (sbc) RUN(norm_bwd_ln_params(sbc, g.B, Co, ns.dw, ns.db, wst));
             } else if (wb) { wscr = c.alloc(wb); NEED(wscr); }
             if (w16) RUN(conv_wgrad16(g, dt, in->d, dyp, W.dw, W.db, wscr, wst, in->dt, dy_st));
             else {
@@ -607,6 +797,63 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         c.top = mark0;
         return ACLGAN_OK;
     }, {{train_w ? W.dw : nullptr, W.nw}, {train_w ? W.db : nullptr, W.nb}, {ln_train ? ns.dw : nullptr, Co}, {ln_train ? ns.db : nullptr, Co}});
+    return ACLGAN_OK;
+}
+
+// Batched Winograd filter transforms (round 5).  The 2 * n_res ResBlock filters of an encoder / a decoder have one shape and sit at a
+// constant distance in the flat parameter buffer (weight + bias, parameters() order): their transforms U = G g G^T for the whole update --
+// forward and, when the generators are trained, input gradient -- are ONE launch per (network, encoder | decoder, direction) at the start
+// of the update instead of one per filter at its first use (96 launches of 6 - 16 us per step at 256 x 256 B = 8).  They are written on lane 0
+// before any other lane starts.  Layout and cache key are exactly what the layers will ask for (conv_wino_u_variant); a layer that asks for
+// something else finds no entry and transforms its own filter as before.
+static int prefill_wino_u(aclgan_ctx& c, int net, int B, int H, int W, bool train) {
+    if (!aclgan_ctx::ucache_enabled() || !u_batch_setting()) return ACLGAN_OK;
+    const aclgan_arch& a = c.arch;
+    const int nd = a.gen_n_downsample, count = 2 * a.gen_n_res, C = a.gen_dim << nd;
+    if (count < 2) return ACLGAN_OK;
+    aclgan_conv_desc d;
+    d.B = B; d.Hi = H >> nd; d.Wi = W >> nd; d.Ci = C; d.Co = C; d.k = 3; d.stride = 1; d.pad = 1; d.upsample = 0; d.act = ACLGAN_ACT_NONE;
+    ConvGeom g;
+    if (make_geom(&d, &g)) return ACLGAN_OK;
+    const size_t ubytes = conv_wino_u_bytes(g);
+    if (!ubytes) return ACLGAN_OK;
+    if (c.dtype != ACLGAN_DTYPE_FP32 && c.w16[0] && conv16_eligible(g, 0)) return ACLGAN_OK;      // these layers run on the 16-bit kernels
+    char buf[160];
+    for (int part = 0; part < 2; ++part) {
+        std::vector<const float*> ws;
+        for (int r = 0; r < a.gen_n_res; ++r)
+            for (int j = 0; j < 2; ++j) {
+                if (part == 0) snprintf(buf, sizeof buf, "enc_content.model.%d.model.%d.model.%d.conv.weight", 1 + nd, r, j);
+                else snprintf(buf, sizeof buf, "dec.model.0.model.%d.model.%d.conv.weight", r, j);
+                ws.push_back(c.param(0, net, buf));
+            }
+        if (!ws[0]) continue;
+        const int64_t wstride = ws[1] - ws[0];
+        bool even = wstride > 0;
+        for (int i = 1; i < count && even; ++i) even = ws[i] && ws[i] - ws[i - 1] == wstride;
+        if (!even) continue;
+        for (int dgrad = 0; dgrad <= (train ? 1 : 0); ++dgrad) {
+            // (the forward keeps its input transform for the weight gradient only where neither runs fused: conv_block's rule)
+            const bool keepV = train && !dgrad && conv_fwd_keep_bytes(g) > 0;
+            const int uv = conv_wino_u_variant(g, dgrad, keepV);
+            if (uv < 0 || c.ucache.count(std::make_pair(ws[0], uv & 15))) continue;
+            float* u0 = nullptr;
+            bool contiguous = true;
+            const size_t ustride = (ubytes + 255) & ~(size_t)255;
+            for (int i = 0; i < count; ++i) {
+                float* u = (float*)c.alloc(ubytes);
+                NEED(u);
+                if (i == 0) u0 = u;
+                else if ((char*)u != (char*)u0 + (size_t)i * ustride) contiguous = false;
+                c.ucache[std::make_pair(ws[i], uv & 15)] = aclgan_ctx::UEnt{u, contiguous, uv >> 4, c.cur_lane, c.nck(c.cur_lane)};
+            }
+            if (!contiguous) {          // (cannot happen with the stack allocator; if it ever does, the layers fill their entries themselves)
+                for (int i = 0; i < count; ++i) c.ucache[std::make_pair(ws[i], uv & 15)].filled = false;
+                continue;
+            }
+            RUN(conv_wino_prefill(g, uv, ws[0], wstride, u0, (int64_t)(ustride / sizeof(float)), count, c.st));
+        }
+    }
     return ACLGAN_OK;
 }
 
@@ -640,24 +887,34 @@ static int content_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out)
 static int dense(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int O, int act, Act** out_p) {
     const int B = in->B, I = in->H * in->W * in->C;
     const bool want = train_w || in->need_grad;
+    CHK(c.need(in));
     Act* out = c.new_act(B, 1, 1, O, want);
     NEED(out->d); if (want) NEED(out->g);
     if (!W.w) { set_error("dense: parameters not bound"); return ACLGAN_EINVAL; }
     RUN(linear_fwd(B, I, O, in->d, W.w, W.b, act, out->d, c.st));
     c.count(4.0 * ((double)B * I + (double)O * I + O + (double)B * O) * (want ? 3.0 : 1.0));    // (+ backward: the same operands again, twice)
+    c.wrote(out);
     *out_p = out;
     if (!want) return ACLGAN_OK;
     aclgan_ctx* cp = &c;
     c.push([=]() -> int {
         aclgan_ctx& c = *cp;
         if (!out->gw) return ACLGAN_OK;
+        CHK(c.acq(out));
+        if (in->need_grad) CHK(c.acq(in));
         float* dx = nullptr;
         float* tmp = nullptr;
         const size_t mark = c.top;
         if (in->need_grad) {
             if (in->gw) { tmp = c.allocf((int64_t)B * I); NEED(tmp); dx = tmp; } else dx = in->g;
         }
-        RUN(linear_bwd(B, I, O, in->d, out->d, out->g, W.w, act, dx, train_w ? W.dw : nullptr, train_w ? W.db : nullptr, c.st));
+        // dy *= act'(y), dx on this closure's lane; dw / db (parameter gradients) on the side stream: x and dy stay put until the update ends
+        const bool side = train_w && aclgan_ctx::side_enabled();
+        RUN(linear_bwd(B, I, O, in->d, out->d, out->g, W.w, act, dx, (train_w && !side) ? W.dw : nullptr, (train_w && !side) ? W.db : nullptr, c.st));
+        if (side) {
+            CHK(c.side_fork());
+            RUN(linear_bwd_params(B, I, O, in->d, out->g, W.dw, W.db, c.st2));
+        }
         if (in->need_grad) {
             if (tmp) {
                 // in->g += tmp  (reuse the GAP backward kernel with HW = 1: dx[i] += dy[i])
@@ -694,6 +951,7 @@ static int style_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
     Act* p = c.new_act(h->B, 1, 1, d, want);
     NEED(p->d); if (want) NEED(p->g);
     RUN(gap_fwd(h->B, h->H * h->W, d, h->d, p->d, c.st, h->dt));
+    c.wrote(p);
     c.count((h->dt ? 2.0 : 4.0) * (double)h->numel() * (want ? 2.0 : 1.0));
     if (want) {
         aclgan_ctx* cp = &c;
@@ -701,6 +959,7 @@ static int style_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
         c.push([=]() -> int {
             aclgan_ctx& c = *cp;
             if (!p->gw) return ACLGAN_OK;
+            CHK(c.acq(p)); CHK(c.acq(hh));
             RUN(gap_bwd(hh->B, hh->H * hh->W, hh->C, p->g, hh->g, hh->gw ? 1 : 0, c.st, hh->gdt));
             mark_written(hh);
             return ACLGAN_OK;
@@ -759,13 +1018,18 @@ static int decode(aclgan_ctx& c, int net, bool train, Act* content, Act* style, 
 }
 
 // MsImageDis.forward (networks.py:50-57)
-static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<Act*>* outs) {
+// lane_a / lane_b (round 5): the full-resolution scale runs on lane_a, the pooling chain and the two coarser scales on lane_b -- their
+// launches are a quarter / a sixteenth of the first scale's and fill a few CUs each (9 .. 64 workgroups); next to the first scale's
+// full-chip kernels they cost next to nothing (profiles/r04_microbench_coresidency.txt).  lane_a == lane_b: one queue, as before.
+static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<Act*>* outs, int lane_a = -1, int lane_b = -1) {
     PassScope pass(c, net, "forward");
     const aclgan_arch& a = c.arch;
     char buf[160];
     NormSpec none;
     Act* xin = x;
+    if (lane_a < 0) lane_a = lane_b = c.cur_lane;
     for (int s = 0; s < a.dis_num_scales; ++s) {
+        CHK(c.set_lane(s == 0 ? lane_a : lane_b));
         Act* h = xin;
         int d = a.dis_dim;
         for (int i = 0; i < a.dis_n_layer; ++i) {
@@ -781,16 +1045,20 @@ static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<A
         outs->push_back(o);
         if (s + 1 < a.dis_num_scales) {
             // self.downsample (networks.py:33,53)
+            CHK(c.set_lane(lane_b));
             Act* src = xin;
+            CHK(c.need(src));
             Act* p = c.new_act(src->B, (src->H - 1) / 2 + 1, (src->W - 1) / 2 + 1, src->C, src->need_grad);
             NEED(p->d); if (p->need_grad) NEED(p->g);
             RUN(avgpool3s2_fwd(src->B, src->H, src->W, src->C, src->d, p->d, c.st));
+            c.wrote(p);
             c.count(4.0 * ((double)src->numel() + (double)p->numel()) * (src->need_grad ? 2.0 : 1.0));
             if (src->need_grad) {
                 aclgan_ctx* cp = &c;
                 c.push([=]() -> int {
                     aclgan_ctx& c = *cp;
                     if (!p->gw) return ACLGAN_OK;
+                    CHK(c.acq(p)); CHK(c.acq(src));
                     RUN(avgpool3s2_bwd(src->B, src->H, src->W, src->C, p->g, src->g, src->gw ? 1 : 0, c.st));
                     mark_written(src);
                     return ACLGAN_OK;
@@ -807,18 +1075,25 @@ static int dis_forward(aclgan_ctx& c, int net, bool train, Act* x, std::vector<A
 // same arithmetic per sample, half the launches and twice the rows for the small late layers.  Segment i
 // covers `nb` consecutive samples with its own target / reported weight / gradient scale / loss slot.
 // The loss gradient w.r.t. each scale's map is written at forward time: total = sum_i gscale_i * loss_i is
-// linear in the reported losses.
+// linear in the reported losses.  Round 5: ONE launch for all scales and segments of the call (networks.py:64-67,81-83,96-98
+// loop over the scales in Python), the terms added to their slots in the order of the former per-term launches.
 struct LsSeg { float target, weight, gscale; float* slot; };
-static int dis_lsgan(aclgan_ctx& c, int net, bool train, Act* x, int nb, const std::vector<LsSeg>& segs) {
+static int dis_lsgan(aclgan_ctx& c, int net, bool train, Act* x, int nb, const std::vector<LsSeg>& segs, int lane_a = -1, int lane_b = -1) {
     std::vector<Act*> outs;
-    CHK(dis_forward(c, net, train, x, &outs));
+    CHK(dis_forward(c, net, train, x, &outs, lane_a, lane_b));
+    std::vector<LsganTerm> terms;
     for (Act* o : outs) {
+        CHK(c.need(o));
         const int n = nb * o->H * o->W * o->C;
-        for (size_t i = 0; i < segs.size(); ++i)
-            RUN(lsgan_loss(o->d + (size_t)i * n, n, segs[i].target, segs[i].weight, segs[i].slot,
-                           o->need_grad ? o->g + (size_t)i * n : nullptr, segs[i].gscale, c.st, c.lscale));
+        for (size_t i = 0; i < segs.size(); ++i) {
+            LsganTerm t;
+            t.o = o->d + (size_t)i * n; t.d_o = o->need_grad ? o->g + (size_t)i * n : nullptr; t.slot = segs[i].slot;
+            t.n = n; t.target = segs[i].target; t.weight = segs[i].weight; t.gscale = segs[i].gscale;
+            terms.push_back(t);
+        }
         if (o->need_grad) mark_written(o);
     }
+    RUN(lsgan_loss_batch(terms.data(), (int)terms.size(), c.st, c.lscale));
     return ACLGAN_OK;
 }
 
@@ -826,6 +1101,7 @@ static int dis_lsgan(aclgan_ctx& c, int net, bool train, Act* x, int nb, const s
 // out_dst / pair_dst: optional pre-made destinations (batch-slice views of joint discriminator inputs)
 static int blend(aclgan_ctx& c, Act* dec4, Act* bg, Act* pair_first, Act** out_p, Act** pair_p, Act* out_dst = nullptr, Act* pair_dst = nullptr) {
     const bool want = dec4->need_grad;
+    CHK(c.need(dec4)); CHK(c.need(bg)); CHK(c.need(pair_first));
     Act* out = out_dst;
     if (!out) {
         out = c.new_act(dec4->B, dec4->H, dec4->W, 3, want);
@@ -843,6 +1119,7 @@ static int blend(aclgan_ctx& c, Act* dec4, Act* bg, Act* pair_first, Act** out_p
     if (plain) RUN(plain_pair_fwd(dec4->B, dec4->H * dec4->W, dec4->d, out->d, pair_first ? pair_first->d : nullptr, pair ? pair->d : nullptr, c.st));
     else RUN(focus_blend_fwd(dec4->B, dec4->H * dec4->W, dec4->d, bg->d, out->d, pair_first ? pair_first->d : nullptr, pair ? pair->d : nullptr, c.st));
     c.count(4.0 * (double)dec4->B * dec4->H * dec4->W * ((plain ? 3 : 4 + 3) + 3 + (pair_first ? 9 : 0)) * (want ? 2.0 : 1.0));
+    c.wrote(out); c.wrote(pair);
     *out_p = out;
     if (pair_p) *pair_p = pair;
     if (!want) return ACLGAN_OK;
@@ -852,6 +1129,10 @@ static int blend(aclgan_ctx& c, Act* dec4, Act* bg, Act* pair_first, Act** out_p
         const float* dout = out->written() ? out->g : nullptr;
         const float* dpair = (pair && pair->written()) ? pair->g : nullptr;
         if (!dout && !dpair) return ACLGAN_OK;
+        if (dout) CHK(c.acq(out));
+        if (dpair) CHK(c.acq(pair));
+        CHK(c.acq(dec4));
+        if (!plain && bg->need_grad) CHK(c.acq(bg));
         if (plain) { RUN(plain_pair_bwd(dec4->B, dec4->H * dec4->W, dout, dpair, dec4->g, c.st)); return ACLGAN_OK; }
         float* dbg = bg->need_grad ? bg->g : nullptr;
         RUN(focus_blend_bwd(dec4->B, dec4->H * dec4->W, dec4->d, bg->d, dout, dpair, dec4->g, dbg, bg->gw ? 1 : 0, c.st));
@@ -929,7 +1210,7 @@ static void fire_bucket(aclgan_ctx& c, int b) {
     const int64_t n = std::min<int64_t>(c.bucket_elems, c.groups[c.trained].numel - off);
     c.bucket_fn(c.bucket_user, c.trained, b, off, n);
 }
-static int run_tape(aclgan_ctx& c) {
+static int run_tape_impl(aclgan_ctx& c) {
     const size_t n = c.tape.size();
     const bool buckets = c.trained >= 0 && c.bucket_elems > 0;
     std::vector<std::vector<int>> done_at;
@@ -948,23 +1229,42 @@ static int run_tape(aclgan_ctx& c) {
             else done_at[first[b]].push_back(b);
         }
     }
+    // the loss kernels ran on lane 0 after it had joined every lane: from here every lane may read everything of the forward pass
+    // (activations, statistics, the gradients the loss kernels wrote) and reuse any scratch
+    CHK(c.lanes_barrier());
     const bool marks = Roctx::get().on && !c.dry && c.tape_pass.size() == n;
-    int open = -1;
+    int open = -1, last_pass = -2;
     for (size_t i = n; i-- > 0;) {
         if (marks && c.tape_pass[i] != open) {      // consecutive closures of one forward pass = one backward range
-            if (open >= 0) { Roctx::get().pop(); Roctx::get().push(("~end@" + std::to_string(g_launches)).c_str()); Roctx::get().pop(); }
+            if (open >= 0) { Roctx::get().pop(); Roctx::get().push(("~end@" + std::to_string((long long)g_launches)).c_str()); Roctx::get().pop(); }
             open = c.tape_pass[i];
-            if (open >= 0) Roctx::get().push(("bwd:" + c.pass_names[open] + "@" + std::to_string(g_launches)).c_str());
+            if (open >= 0) Roctx::get().push(("bwd:" + c.pass_names[open] + "@" + std::to_string((long long)g_launches)).c_str());
         }
-        const int rc_i = c.tape[i].fn();
+        // a closure runs on the lane of the forward pass that recorded it; a checkpoint at every pass boundary keeps the waits of
+        // consumers on other lanes exact (they wait for the end of the producing pass, not for whatever that lane was given afterwards)
+        if (c.tape[i].pass != last_pass) { if (last_pass != -2) CHK(c.mark()); last_pass = c.tape[i].pass; }
+        CHK(c.set_lane(c.tape[i].lane));
+        int rc_i = c.tape[i].fn();
+        if (!rc_i && !c.dry && fault_at_setting() >= 0 && (int)(n - 1 - i) == fault_at_setting()) { set_error("injected fault after backward closure %d (tuning key fault_at)", fault_at_setting()); rc_i = ACLGAN_EHIP; }
         if (rc_i) { if (marks && open >= 0) Roctx::get().pop(); return rc_i; }
         if (buckets && !done_at[i].empty()) {
-            CHK(c.side_join());             // a bucket handed to the all-reduce must hold its side-stream weight gradients too
+            // a bucket handed to the all-reduce must hold everything written into it: the side stream's parameter gradients, and the
+            // caller's stream (lane 0, the one its communication stream orders after) must have seen every lane
+            const int lane = c.cur_lane;
+            CHK(c.lanes_join());
             for (int b : done_at[i]) fire_bucket(c, b);
+            CHK(c.set_lane(lane));
         }
     }
-    if (marks && open >= 0) { Roctx::get().pop(); Roctx::get().push(("~end@" + std::to_string(g_launches)).c_str()); Roctx::get().pop(); }
-    return c.side_join();
+    if (marks && open >= 0) { Roctx::get().pop(); Roctx::get().push(("~end@" + std::to_string((long long)g_launches)).c_str()); Roctx::get().pop(); }
+    return c.lanes_join();
+}
+static int run_tape(aclgan_ctx& c) {
+    const int rc = run_tape_impl(c);
+    // an error leaves closures half enqueued on lanes / the side stream: nothing may still be in flight there when the caller is told
+    // (it will reuse or free the workspace)
+    if (rc) c.lanes_quiesce();
+    return rc;
 }
 
 static int check_shape(const aclgan_ctx& c, int B, int H, int W) {
@@ -995,6 +1295,7 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         hipError_t e = hipMemsetAsync(L, 0, sizeof(float) * (ACLGAN_L_GEN_TOTAL + 1), c.st);
         if (e != hipSuccess) return hip_fail(e, "memset losses");
     }
+    CHK(c.lanes_begin(lanes_setting()));
     CHK(pack_params(c));
     Act *xa, *xb, *z1, *z2, *z3;
     CHK(input_act(c, x_a, B, 3, H, W, &xa));
@@ -1002,31 +1303,48 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     CHK(wrap_vec(c, z, B, sd, 1.f, &z1));
     CHK(wrap_vec(c, z + (size_t)B * sd, B, sd, hp.alpha, &z2));   // alpha multiplies only z_2 (trainer.py:109)
     CHK(wrap_vec(c, z + (size_t)2 * B * sd, B, sd, 1.f, &z3));
+    // the Winograd transforms of all ResBlock filters this update will use: one batched launch per (network, encoder | decoder,
+    // forward | input gradient) instead of one per filter and use
+    CHK(prefill_wino_u(c, AB, B, H, W, true)); CHK(prefill_wino_u(c, BA, B, H, W, true));
     Act *c1, *c2, *s2, *c4, *s4, *c3;
-    CHK(content_encode(c, AB, true, xa, &c1));                      // trainer.py:103 (style dropped)
-    CHK(content_encode(c, BA, true, xa, &c2));                      // trainer.py:104
-    CHK(style_encode(c, BA, true, xa, &s2));
-    CHK(content_encode(c, AB, true, xb, &c4));                      // trainer.py:105
-    CHK(style_encode(c, AB, true, xb, &s4));
     Act *dB4, *dA4, *xB, *xA, *pA1, *rA4, *rB4, *dA24, *xA2, *pA2;
     // joint discriminator inputs: (x_A_fake | x_A2_fake) for dis_A, (pair_A1 | pair_A2) for dis_2
     Act* jA = c.new_act(2 * B, H, W, 3, true);
     Act* jP = c.new_act(2 * B, H, W, 6, true);
     NEED(jA->d); NEED(jA->g); NEED(jP->d); NEED(jP->g);
-    CHK(decode(c, AB, true, c1, z1, &dB4)); CHK(zero_grad_of(c, dB4));   // trainer.py:108
-    CHK(decode(c, BA, true, c2, z2, &dA4)); CHK(zero_grad_of(c, dA4));   // trainer.py:109
-    CHK(blend(c, dB4, xa, nullptr, &xB, nullptr));                   // trainer.py:110
-    CHK(blend(c, dA4, xa, xa, &xA, &pA1, c.new_view(jA, 0, B), c.new_view(jP, 0, B)));   // trainer.py:111,132
-    CHK(decode(c, BA, true, c2, s2, &rA4)); CHK(zero_grad_of(c, rA4));   // trainer.py:113
-    CHK(decode(c, AB, true, c4, s4, &rB4)); CHK(zero_grad_of(c, rB4));   // trainer.py:114
-    CHK(content_encode(c, BA, true, xB, &c3));                      // trainer.py:125
-    CHK(decode(c, BA, true, c3, z3, &dA24)); CHK(zero_grad_of(c, dA24)); // trainer.py:127
-    CHK(blend(c, dA24, xB, xa, &xA2, &pA2, c.new_view(jA, B, B), c.new_view(jP, B, B)));   // trainer.py:128,133
-    // adversarial terms (trainer.py:136-139); discriminators frozen
-    CHK(dis_lsgan(c, ACLGAN_NET_DIS_A, false, jA, B, {{1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}, {1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}}));
-    CHK(dis_lsgan(c, ACLGAN_NET_DIS_B, false, xB, B, {{1.f, 1.f, hp.gan_w, L + ACLGAN_L_GEN_ADV_B}}));
-    CHK(dis_lsgan(c, ACLGAN_NET_DIS_2, false, jP, B, {{1.f, 1.f, hp.gan_cw, L + ACLGAN_L_GEN_ADV_2},     // networks.py:98: pair_A1 -> 1
-                                                        {0.f, 1.f, hp.gan_cw, L + ACLGAN_L_GEN_ADV_2}}));  //                 pair_A2 -> 0
+    // Lanes (round 5).  Lane 0 carries the chain everything else waits for: x_a -> gen_AB -> x_B_fake -> gen_BA -> x_A2_fake
+    // (trainer.py:103,108,110,125-128); lane 1 the other translation direction and the two reconstructions (trainer.py:104-105,109,111,
+    // 113-114), which only meet the chain again in the discriminators.  One lane: the same host order on one queue.
+    const int L0 = 0, L1 = 1;
+#define PASS(expr) do { CHK(expr); CHK(c.mark()); } while (0)
+    CHK(c.mark());                                                    // (the preamble: inputs, noise, filter transforms)
+    CHK(c.set_lane(L0));
+    PASS(content_encode(c, AB, true, xa, &c1));                      // trainer.py:103 (style dropped)
+    CHK(c.set_lane(L1));
+    PASS(content_encode(c, BA, true, xa, &c2));                      // trainer.py:104
+    PASS(style_encode(c, BA, true, xa, &s2));
+    CHK(c.set_lane(L0));
+    PASS(decode(c, AB, true, c1, z1, &dB4)); CHK(zero_grad_of(c, dB4));   // trainer.py:108
+    PASS(blend(c, dB4, xa, nullptr, &xB, nullptr));                  // trainer.py:110
+    CHK(c.set_lane(L1));
+    PASS(decode(c, BA, true, c2, z2, &dA4)); CHK(zero_grad_of(c, dA4));   // trainer.py:109
+    PASS(blend(c, dA4, xa, xa, &xA, &pA1, c.new_view(jA, 0, B), c.new_view(jP, 0, B)));   // trainer.py:111,132
+    CHK(c.set_lane(L0));
+    PASS(content_encode(c, BA, true, xB, &c3));                      // trainer.py:125
+    PASS(decode(c, BA, true, c3, z3, &dA24)); CHK(zero_grad_of(c, dA24)); // trainer.py:127
+    PASS(blend(c, dA24, xB, xa, &xA2, &pA2, c.new_view(jA, B, B), c.new_view(jP, B, B)));   // trainer.py:128,133
+    CHK(c.set_lane(L1));
+    PASS(decode(c, BA, true, c2, s2, &rA4)); CHK(zero_grad_of(c, rA4));   // trainer.py:113
+    PASS(content_encode(c, AB, true, xb, &c4));                      // trainer.py:105
+    PASS(style_encode(c, AB, true, xb, &s4));
+    PASS(decode(c, AB, true, c4, s4, &rB4)); CHK(zero_grad_of(c, rB4));   // trainer.py:114
+    // adversarial terms (trainer.py:136-139); discriminators frozen.  dis_B only needs x_B_fake: it is enqueued first; each pass runs its
+    // full-resolution scale on one lane and the coarser scales on the other
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_B, false, xB, B, {{1.f, 1.f, hp.gan_w, L + ACLGAN_L_GEN_ADV_B}}, L1, L0));
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_A, false, jA, B, {{1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}, {1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}}, L0, L1));
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_2, false, jP, B, {{1.f, 1.f, hp.gan_cw, L + ACLGAN_L_GEN_ADV_2},     // networks.py:98: pair_A1 -> 1
+                                                        {0.f, 1.f, hp.gan_cw, L + ACLGAN_L_GEN_ADV_2}}, L1, L0));  //                 pair_A2 -> 0
+    CHK(c.lanes_join());                                              // the loss kernels below read all of it, on lane 0
     // focus losses (trainer.py:145-161)
     const int64_t npix = (int64_t)B * H * W;
     const float fscale = hp.focus_loss / (float)H / (float)W / (float)B / 3.f;
@@ -1079,6 +1397,7 @@ static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         hipError_t e = hipMemsetAsync(L + ACLGAN_L_DIS_A, 0, sizeof(float) * 4, c.st);
         if (e != hipSuccess) return hip_fail(e, "memset losses");
     }
+    CHK(c.lanes_begin(lanes_setting()));
     CHK(pack_params(c));
     Act *xa, *xb, *z1, *z2, *z3;
     CHK(input_act(c, x_a, B, 3, H, W, &xa));
@@ -1086,6 +1405,7 @@ static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     CHK(wrap_vec(c, z, B, sd, 1.f, &z1));
     CHK(wrap_vec(c, z + (size_t)B * sd, B, sd, hp.alpha, &z2));
     CHK(wrap_vec(c, z + (size_t)2 * B * sd, B, sd, 1.f, &z3));
+    CHK(prefill_wino_u(c, AB, B, H, W, false)); CHK(prefill_wino_u(c, BA, B, H, W, false));
     Act *c1, *c2, *c3, *dB4, *dA4, *dA24, *xB, *xA, *xA2, *pA1, *pA2;
     // joint discriminator inputs: dis_A sees (x_A_fake | x_A2_fake | x_a), dis_B (x_B_fake | x_b), dis_2 (pair_A1 | pair_A2)
     Act* jA = c.new_act(3 * B, H, W, 3, false);
@@ -1097,26 +1417,37 @@ static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         if (e == hipSuccess) e = hipMemcpyAsync(jB->d + (size_t)xb->numel(), xb->d, sizeof(float) * xb->numel(), hipMemcpyDeviceToDevice, c.st);
         if (e != hipSuccess) return hip_fail(e, "copy real images into the joint discriminator batch");
     }
-    CHK(content_encode(c, AB, false, xa, &c1));
-    CHK(content_encode(c, BA, false, xa, &c2));
-    CHK(decode(c, AB, false, c1, z1, &dB4));
-    CHK(decode(c, BA, false, c2, z2, &dA4));
-    CHK(blend(c, dB4, xa, nullptr, &xB, nullptr, c.new_view(jB, 0, B), nullptr));
-    CHK(blend(c, dA4, xa, xa, &xA, &pA1, c.new_view(jA, 0, B), c.new_view(jP, 0, B)));
-    CHK(content_encode(c, BA, false, xB, &c3));
-    CHK(decode(c, BA, false, c3, z3, &dA24));
-    CHK(blend(c, dA24, xB, xa, &xA2, &pA2, c.new_view(jA, B, B), c.new_view(jP, B, B)));
+    // lanes as in gen_update: lane 0 = the chain x_a -> gen_AB -> x_B_fake -> gen_BA -> x_A2_fake, lane 1 = the other direction, then
+    // dis_B (which needs only x_B_fake) next to the second half of the chain
+    const int L0 = 0, L1 = 1;
+    CHK(c.mark());
+    CHK(c.set_lane(L0));
+    PASS(content_encode(c, AB, false, xa, &c1));
+    CHK(c.set_lane(L1));
+    PASS(content_encode(c, BA, false, xa, &c2));
+    CHK(c.set_lane(L0));
+    PASS(decode(c, AB, false, c1, z1, &dB4));
+    PASS(blend(c, dB4, xa, nullptr, &xB, nullptr, c.new_view(jB, 0, B), nullptr));
+    CHK(c.set_lane(L1));
+    PASS(decode(c, BA, false, c2, z2, &dA4));
+    PASS(blend(c, dA4, xa, xa, &xA, &pA1, c.new_view(jA, 0, B), c.new_view(jP, 0, B)));
     // calc_dis_loss(fake -> 0, real -> 1) (networks.py:60-67; trainer.py:283-286)
-    CHK(dis_lsgan(c, ACLGAN_NET_DIS_A, true, jA, B, {{0.f, 0.5f, hp.gan_w, L + ACLGAN_L_DIS_A}, {0.f, 0.5f, hp.gan_w, L + ACLGAN_L_DIS_A},
-                                                       {1.f, 1.0f, hp.gan_w, L + ACLGAN_L_DIS_A}}));   // the real branch occurs twice x 0.5
-    CHK(dis_lsgan(c, ACLGAN_NET_DIS_B, true, jB, B, {{0.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}, {1.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}}));
-    CHK(dis_lsgan(c, ACLGAN_NET_DIS_2, true, jP, B, {{0.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}, {1.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}}));
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_B, true, jB, B, {{0.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}, {1.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}}, L1, L1));
+    CHK(c.set_lane(L0));
+    PASS(content_encode(c, BA, false, xB, &c3));
+    PASS(decode(c, BA, false, c3, z3, &dA24));
+    PASS(blend(c, dA24, xB, xa, &xA2, &pA2, c.new_view(jA, B, B), c.new_view(jP, B, B)));
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_A, true, jA, B, {{0.f, 0.5f, hp.gan_w, L + ACLGAN_L_DIS_A}, {0.f, 0.5f, hp.gan_w, L + ACLGAN_L_DIS_A},
+                                                       {1.f, 1.0f, hp.gan_w, L + ACLGAN_L_DIS_A}}, L0, L1));   // the real branch occurs twice x 0.5
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_2, true, jP, B, {{0.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}, {1.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}}, L1, L0));
+    CHK(c.lanes_join());
     if (!c.dry) {
         hipLaunchKernelGGL(dis_total_kernel, dim3(1), dim3(1), 0, c.st, L, hp);
         ACL_CHECK_LAUNCH("dis_total_kernel");
     }
     return run_tape(c);   // loss_dis_total.backward() (trainer.py:292)
 }
+#undef PASS
 
 }  // namespace aclgan
 
@@ -1195,26 +1526,50 @@ int aclgan_bind_params(aclgan_ctx* ctx, int group, float* param, float* grad, fl
     return ACLGAN_OK;
 }
 
+// bytes one update needs (which: 0 gen_update, 1 dis_update) with the switches as they are now: a dry run of the same scheduler
+static int update_need_bytes(aclgan_ctx& c, int which, int B, int H, int W, size_t* out) {
+    aclgan_hparams hp;
+    memset(&hp, 0, sizeof hp);
+    hp.focus_loss = c.arch.gen_output_dim == 4 ? 1.f : 0.f; hp.alpha = 1.f;      // (the branch the architecture can run: gen.output_dim 4 = focus, 3 = non-focus)
+    c.reset_step();
+    c.dry = true; c.peak = 0; c.peak2 = 0; c.trained = -1;
+    const aclgan_bucket_fn keep = c.bucket_fn;
+    c.bucket_fn = nullptr;
+    const int rc = which == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)
+                              : dis_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr);
+    c.bucket_fn = keep;
+    c.dry = false; c.trained = -1;
+    *out = c.peak + c.peak2 + 512;
+    c.reset_step();
+    return rc;
+}
 int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out) {
     ACL_REQUIRE(ctx && out, "null argument");
     aclgan_ctx& c = *ctx;
     ACL_REQUIRE(c.groups[0].param && c.groups[1].param, "bind parameters first");
-    aclgan_hparams hp;
-    memset(&hp, 0, sizeof hp);
-    hp.focus_loss = c.arch.gen_output_dim == 4 ? 1.f : 0.f; hp.alpha = 1.f;      // (the branch the architecture can run: gen.output_dim 4 = focus, 3 = non-focus)
     size_t best = 0;
     for (int which = 0; which < 2; ++which) {
-        c.reset_step();
-        c.dry = true; c.peak = 0; c.peak2 = 0; c.trained = -1;
-        int rc = which == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)
-                            : dis_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr);
-        c.dry = false; c.trained = -1;
-        const size_t pk = c.peak + c.peak2 + 512;
-        c.reset_step();
+        size_t pk = 0;
+        const int rc = update_need_bytes(c, which, B, H, W, &pk);
         if (rc) return rc;
         if (pk > best) best = pk;
     }
     *out = best + 4096;
+    return ACLGAN_OK;
+}
+// ACLGAN_OK iff the bound workspace holds both updates at this shape with the switches as they are now; ACLGAN_ENOMEM (with the two sizes
+// in the message) otherwise.  No launches: callable without a GPU.  The update entry points make the same check themselves (once per
+// shape and switch setting) before they enqueue anything.
+int aclgan_check_workspace(aclgan_ctx* ctx, int B, int H, int W) {
+    ACL_REQUIRE(ctx, "null ctx");
+    ACL_REQUIRE(ctx->groups[0].param && ctx->groups[1].param, "bind parameters first");
+    size_t need = 0;
+    const int rc = aclgan_workspace_bytes(ctx, B, H, W, &need);
+    if (rc) return rc;
+    if (!ctx->ws || ctx->ws_bytes < need) {
+        set_error("workspace too small: bound %zu bytes, aclgan_workspace_bytes(%d, %d, %d) = %zu", ctx->ws ? ctx->ws_bytes : (size_t)0, B, H, W, need);
+        return ACLGAN_ENOMEM;
+    }
     return ACLGAN_OK;
 }
 int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int W, double* out) {
@@ -1280,35 +1635,54 @@ int aclgan_bind_workspace(aclgan_ctx* ctx, void* workspace, size_t bytes) {
     return ACLGAN_OK;
 }
 
-static int step_common(aclgan_ctx* ctx, const float* x_a, const float* x_b, const float* z, const aclgan_hparams* hp, float* losses, void* stream, int group_trained) {
+static int step_common(aclgan_ctx* ctx, const float* x_a, const float* x_b, const float* z, const aclgan_hparams* hp, float* losses, void* stream, int group_trained,
+                       int B, int H, int W) {
     ACL_REQUIRE(ctx && x_a && x_b && z && hp && losses, "null argument");
     ACL_REQUIRE(ctx->ws, "bind a workspace first (aclgan_workspace_bytes / aclgan_bind_workspace)");
     ACL_REQUIRE(ctx->groups[0].param && ctx->groups[1].param, "bind parameters first");
     ACL_REQUIRE(ctx->groups[group_trained].grad, "gradient buffer of the trained group is not bound");
+    // the bound workspace against this update's need (a dry run, cached per shape / dtype / switch setting): an undersized workspace is
+    // refused here, before anything is enqueued (the allocator checks every request as well)
+    if (check_shape(*ctx, B, H, W) == ACLGAN_OK) {
+        const aclgan_ctx::NeedKey key{group_trained, B, H, W, ctx->dtype, tuning_epoch(), deterministic() ? 1 : 0, ctx->bucket_elems > 0 ? 1 : 0};
+        auto it = ctx->need_cache.find(key);
+        if (it == ctx->need_cache.end()) {
+            size_t need = 0;
+            const int rc = update_need_bytes(*ctx, group_trained, B, H, W, &need);
+            if (rc) return rc;
+            it = ctx->need_cache.emplace(key, need).first;
+        }
+        if (it->second > ctx->ws_bytes) {
+            set_error("workspace too small: bound %zu bytes, this update needs %zu (aclgan_workspace_bytes)", ctx->ws_bytes, it->second);
+            return ACLGAN_ENOMEM;
+        }
+    }
     ctx->reset_step();
-    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0; ctx->trained = group_trained;
+    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0; ctx->peak2 = 0; ctx->trained = group_trained;
     return ACLGAN_OK;
 }
 
 int aclgan_gen_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const float* z, int B, int H, int W,
                       const aclgan_hparams* hp, float* losses, void* stream) {
-    int rc = step_common(ctx, x_a, x_b, z, hp, losses, stream, 0);
+    int rc = step_common(ctx, x_a, x_b, z, hp, losses, stream, 0, B, H, W);
     if (rc) return rc;
     ctx->ucache_hook = WinoUCache{ctx, &aclgan_ctx::ucache_lookup};
     set_wino_ucache(&ctx->ucache_hook);
     rc = gen_update_impl(*ctx, x_a, x_b, z, B, H, W, *hp, losses);
     set_wino_ucache(nullptr);
+    if (rc) ctx->lanes_quiesce();      // (an error in the middle of the forward: lanes may hold work)
     ctx->reset_step();
     return rc;
 }
 int aclgan_dis_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const float* z, int B, int H, int W,
                       const aclgan_hparams* hp, float* losses, void* stream) {
-    int rc = step_common(ctx, x_a, x_b, z, hp, losses, stream, 1);
+    int rc = step_common(ctx, x_a, x_b, z, hp, losses, stream, 1, B, H, W);
     if (rc) return rc;
     ctx->ucache_hook = WinoUCache{ctx, &aclgan_ctx::ucache_lookup};
     set_wino_ucache(&ctx->ucache_hook);
     rc = dis_update_impl(*ctx, x_a, x_b, z, B, H, W, *hp, losses);
     set_wino_ucache(nullptr);
+    if (rc) ctx->lanes_quiesce();
     ctx->reset_step();
     return rc;
 }

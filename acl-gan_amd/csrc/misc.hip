@@ -318,6 +318,13 @@ int linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, c
     return ACLGAN_OK;
 }
 
+int linear_bwd_params(int B, int I, int O, const float* x, const float* dy, float* dw, float* db, hipStream_t st) {
+    if (!dw) return ACLGAN_OK;
+    hipLaunchKernelGGL(linear_dw_kernel, dim3((unsigned)cdiv64((int64_t)O * I, 256)), dim3(256), 0, st, x, dy, dw, db, B, I, O);
+    ACL_CHECK_LAUNCH("linear_dw_kernel");
+    return ACLGAN_OK;
+}
+
 // ---- global average pool ----
 __global__ void gap_fwd_kernel(const void* __restrict__ x, int xst, float* __restrict__ y, int HW, int C) {
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
@@ -526,6 +533,36 @@ __global__ void __launch_bounds__(256) lsgan_kernel(const float* __restrict__ o,
 int lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, hipStream_t st, const float* lscale) {
     hipLaunchKernelGGL(lsgan_kernel, dim3(1), dim3(256), 0, st, o, n, target, weight, loss_slot, d_o, gscale, lscale);
     ACL_CHECK_LAUNCH("lsgan_kernel");
+    return ACLGAN_OK;
+}
+
+struct LsganBatch { LsganTerm t[LSGAN_MAX_TERMS]; int n; };
+__global__ void __launch_bounds__(256) lsgan_batch_kernel(LsganBatch b, const float* __restrict__ lscale) {
+    const float ls = lscale ? lscale[0] : 1.f;
+    for (int k = 0; k < b.n; ++k) {
+        const LsganTerm t = b.t[k];
+        float s = 0.f;
+        float gscale = t.gscale;
+        if (lscale) gscale *= ls;
+        const float kk = gscale * t.weight * 2.f / (float)t.n;
+        for (int i = threadIdx.x; i < t.n; i += 256) {
+            const float d = t.o[i] - t.target;
+            s = fmaf(d, d, s);
+            if (t.d_o) t.d_o[i] = kk * d;
+        }
+        s = block_sum_t0(s);
+        if (threadIdx.x == 0) t.slot[0] += t.weight * s / (float)t.n;      // one workgroup, terms in order: plain adds, same values as lsgan_kernel's
+        __syncthreads();
+    }
+}
+int lsgan_loss_batch(const LsganTerm* terms, int nterms, hipStream_t st, const float* lscale) {
+    for (int k0 = 0; k0 < nterms; k0 += LSGAN_MAX_TERMS) {
+        LsganBatch b;
+        b.n = std::min(LSGAN_MAX_TERMS, nterms - k0);
+        for (int k = 0; k < b.n; ++k) b.t[k] = terms[k0 + k];
+        hipLaunchKernelGGL(lsgan_batch_kernel, dim3(1), dim3(256), 0, st, b, lscale);
+        ACL_CHECK_LAUNCH("lsgan_batch_kernel");
+    }
     return ACLGAN_OK;
 }
 

@@ -183,6 +183,11 @@ int aclgan_bind_loss_scale(aclgan_ctx* ctx, float* state);
 /* activation workspace for one update at the given batch shape (bytes); bind before stepping */
 int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out);
 int aclgan_bind_workspace(aclgan_ctx* ctx, void* workspace, size_t bytes);
+/* ACLGAN_OK iff the bound workspace holds both updates at this batch shape with the tuning switches as they are now, else ACLGAN_ENOMEM
+ * with both sizes in aclgan_last_error().  Launches nothing (usable without a GPU).  aclgan_gen_update / aclgan_dis_update make the same
+ * check before they enqueue anything, and the arena refuses every single request that would leave the bound range (round 5: an
+ * undersized workspace fails, it never corrupts). */
+int aclgan_check_workspace(aclgan_ctx* ctx, int B, int H, int W);
 /* arena for ONE forward-only call below (encode / decode / discriminator forward) on (B,*,H,W) images: what
  * test.py:55-131 and trainer.sample need -- far smaller than a training step's, and without its shape constraints
  * (any H, W the networks accept, e.g. the 256x340 a Resize(256) of a non-square photo yields) */
@@ -308,8 +313,18 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
  * key "wino_wgrad_fused" (round 4): 0 = their weight gradient runs as the seven-launch pipeline of csrc/conv_wino.hip, 1 (default) / 2 = as the
  * one-kernel Winograd weight gradient (csrc/conv_wino_wgrad_fused.hip) wherever the shape is eligible (W a multiple of 16, H of 4, Cout of 64,
  * Cin of 32).
- * Returns the previous value, -1 for an unknown key.  Not thread-safe against running launches. */
+ * key "lanes" (round 5): 1 .. 4 HIP streams the independent branches of an update are spread over (the two translation directions,
+ * the reconstruction decodes, the discriminators and their scales: reference trainer.py:103-139, 258-286; csrc/engine.hip "Lanes");
+ * 1 = one queue (the round-4 plan), default 2 (ACLGAN_LANES).  Results do not depend on it.  key "u_batch" (round 5): 1 (default) =
+ * the Winograd transforms of all ResBlock filters of a network are one launch at the start of an update, 0 = one launch per filter at
+ * its first use.  key "fault_at" (test hook; -1 = off): the backward replay of the next updates fails with ACLGAN_EHIP after that many
+ * closures have been enqueued -- exercises the error path (all internal streams drained before the call returns).
+ * Returns the previous value, -1 for an unknown key.  The switches are atomics (a concurrent update sees the old or the new value, never a
+ * torn one), but changing one WHILE an update is being enqueued changes that update's plan half way: do not. */
 int aclgan_set_tuning(const char* key, int value);
+/* The same switches with the status in the return value (round 5): ACLGAN_OK and the previous setting through *previous (may be NULL), or
+ * ACLGAN_EINVAL for an unknown key (aclgan_set_tuning cannot tell -1 "unknown" from a previous value). */
+int aclgan_tuning(const char* key, int value, int* previous);
 /* The same launch with the normalisation statistics taken from its epilogue (round 3; replaces the norm_stats pass over y that
  * follows the conv in reference networks.py:382-395 Conv2dBlock.forward -> self.norm).  aclgan_conv2d_fwd16s_stats_chunk = rows R per
  * statistics chunk (the launch's row tile: 128 or 256; 0 = not offered: Ho * Wo must be a multiple of R).  stats receives
@@ -400,6 +415,12 @@ int aclgan_focus_translation_nchw(const float* fg, int64_t fg_bstride, const flo
 /* MsImageDis.calc_*_loss, one scale (networks.py:67,83,98): *loss_slot += weight*mean((o-target)^2);
  * d_o (may be NULL) = gscale*weight*2(o-target)/n */
 int aclgan_lsgan_loss(const float* o, int n, float target, float weight, float* loss_slot, float* d_o, float gscale, void* stream);
+/* ... and all scales / segments of one MsImageDis.calc_*_loss call in ONE launch (round 5; the reference loops over the scales in Python,
+ * networks.py:64-67,81-83,96-98): nterms terms, arrays indexed by term; d_o (the array or single entries) may be NULL.  The terms are
+ * processed in index order by one workgroup: every slot ends up with exactly the bits the equivalent sequence of aclgan_lsgan_loss
+ * calls leaves there. */
+int aclgan_lsgan_loss_multi(const float* const* o, const int* n, const float* target, const float* weight, float* const* loss_slot,
+                            float* const* d_o, const float* gscale, int nterms, void* stream);
 /* recon_criterion (trainer.py:61-62): *loss_slot += mean|a[..., :3] - b| over npix pixels; a has a_channels (3 or 4) NHWC
  * channels, b has 3; d_a (may be NULL) (+)= gscale*sign/(3*npix) on channels 0-2 */
 int aclgan_l1_loss(const float* a, int a_channels, const float* b, int64_t npix, float* loss_slot, float* d_a, float gscale,

@@ -144,15 +144,19 @@ def test_host_side_under_address_sanitizer(tmp_path):
     error paths -- instrumented by AddressSanitizer (`make -C acl-gan_amd/csrc asan`: host-only objects) and driven in a subprocess under
     the ASan runtime.  Any heap / stack / use-after-free error aborts the child; leaks are not checked (ctypes / Python own the process)."""
     import glob
+    import shutil
     import subprocess
     import sys
     csrc = os.path.join(ROOT, "acl-gan_amd", "csrc")
-    r = subprocess.run(["make", "-C", csrc, "-j8", "asan"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lib = os.path.join(ROOT, "acl-gan_amd", "libaclgan_hip_asan.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
-    if not rt:
-        pytest.skip("no ASan runtime in this image")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)) or not rt:
+        pytest.skip("no hipcc / ASan runtime on this machine: the sanitizer build is a toolchain matter, not a test failure")
+    # built into the test's temporary directory: no artefacts in the source tree
+    asan_dir = str(tmp_path / "asan")
+    r = subprocess.run(["make", "-C", csrc, "-j8", "asan", "ASAN_DIR=" + asan_dir], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lib = os.path.join(asan_dir, "libaclgan_hip_asan.so")
     prog = r'''
 import ctypes as C, sys
 L = C.CDLL(%r)
@@ -191,10 +195,31 @@ for out_dim, dims in ((4, (64, 256, 64)), (3, (8, 16, 8)), (4, (16, 32, 16))):
                     L.aclgan_bucket_schedule(ctx, grp, B, H, W, 0, order, 1, C.byref(cnt))      # capacity too small: an error code, no overrun
     assert L.aclgan_workspace_bytes(ctx, 0, 64, 64, C.byref(C.c_size_t())) != 0
     assert L.aclgan_workspace_bytes(None, 1, 64, 64, C.byref(C.c_size_t())) != 0
+    # round 5: the scheduler with 1 .. 4 lanes (branches of the update on separate streams; dry runs follow the same allocation rules),
+    # and the workspace check: exactly aclgan_workspace_bytes passes, one byte less is ACLGAN_ENOMEM (-4) -- before anything is enqueued
+    prev = C.c_int()
+    for lanes in (1, 2, 3, 4):
+        assert L.aclgan_tuning(b"lanes", lanes, C.byref(prev)) == 0
+        ws = C.c_size_t()
+        assert L.aclgan_workspace_bytes(ctx, 2, 64, 64, C.byref(ws)) == 0 and ws.value > 0
+        fake = C.c_void_p(0x100000)
+        assert L.aclgan_bind_workspace(ctx, fake, C.c_size_t(ws.value)) == 0
+        assert L.aclgan_check_workspace(ctx, 2, 64, 64) == 0, L.aclgan_last_error()
+        assert L.aclgan_bind_workspace(ctx, fake, C.c_size_t(ws.value - 1)) == 0
+        assert L.aclgan_check_workspace(ctx, 2, 64, 64) == -4 and b"too small" in L.aclgan_last_error()
+        for grp in (0, 1):
+            if L.aclgan_set_grad_buckets(ctx, C.c_int64(1 << 16), None, None) == 0:
+                assert L.aclgan_bucket_schedule(ctx, grp, 2, 64, 64, 0, order, 8192, C.byref(cnt)) == 0
+    assert L.aclgan_tuning(b"lanes", 2, None) == 0
     L.aclgan_ctx_destroy(ctx)
 bad = Arch(3, 3, 64, 256, 8, 4, 2, 4, 64, 4, 3); ctx = C.c_void_p()
 assert L.aclgan_ctx_create(C.byref(bad), C.byref(ctx)) != 0 and L.aclgan_last_error()
 assert L.aclgan_set_tuning(b"no such knob", 1) == -1
+prev = C.c_int(12345)
+assert L.aclgan_tuning(b"no such knob", 1, C.byref(prev)) == -1 and prev.value == 12345 and b"unknown key" in L.aclgan_last_error()
+assert L.aclgan_tuning(b"u_batch", 0, C.byref(prev)) == 0 and prev.value in (0, 1)
+assert L.aclgan_tuning(b"u_batch", prev.value, None) == 0
+assert L.aclgan_tuning(None, 1, None) == -1
 assert L.aclgan_launch_count() == 0
 print("ASAN_CHILD_OK")
 ''' % lib

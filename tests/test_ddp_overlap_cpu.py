@@ -78,11 +78,12 @@ def test_bucket_schedule_order_and_coverage():
                 enc = offs[net + "/enc_content.model.1.conv.weight"] // BUCKET
                 assert pos[dec] < pos[enc] and pos[mlp] < pos[enc], (net, pos[dec], pos[mlp], pos[enc])
         else:
-            # dis_update: the three discriminators run A, B, 2 in the forward -> dis_2's buckets complete first
-            first_2 = offs["dis_2/cnns.0.0.conv.weight"] // BUCKET
-            first_A = offs["dis_A/cnns.0.0.conv.weight"] // BUCKET
-            assert pos[first_2] < pos[first_A]
-            assert first_A in order[-2:]
+            # dis_update (round 5 order): dis_B runs first in the forward (it needs only x_B_fake and fills the second lane while
+            # the chain to x_A2_fake is still running), then dis_A, then dis_2 -> dis_2's buckets complete first, dis_B's last.
+            # Compared on layers from the middle of each network (a bucket at a network boundary holds tensors of two of them).
+            mid = {net: offs[net + "/cnns.1.2.conv.weight"] // BUCKET for net in ("dis_A", "dis_B", "dis_2")}
+            assert pos[mid["dis_2"]] < pos[mid["dis_A"]] < pos[mid["dis_B"]], (mid, pos)
+            assert offs["dis_B/cnns.0.0.conv.weight"] // BUCKET in order[-2:]
     L.lib.aclgan_ctx_destroy(ctx)
 
 

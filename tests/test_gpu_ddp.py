@@ -126,8 +126,11 @@ def test_bench_eight_ranks_control_flow_and_overlap_fallback():
     assert out["config"]["grad_allreduce"] == "after backward" and out["config"]["replicas_identical"] is True
 
 
-def test_bucket_callback_fires_after_the_last_writer():
-    """What the overlapped all-reduce relies on: when the engine calls back for a bucket, every kernel that writes that bucket has
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_bucket_callback_fires_after_the_last_writer(lanes):
+    """(round 5: under the branch-parallel replay as well -- `lanes` streams carry the backward closures, the parameter gradients are on
+    their own stream; before a bucket is handed out, lane 0 = the caller's stream has joined all of them: csrc/engine.hip run_tape.)
+    What the overlapped all-reduce relies on: when the engine calls back for a bucket, every kernel that writes that bucket has
     already been ENQUEUED -- a consumer ordered after the compute stream at callback time (ProcessGroupNCCL: the RCCL stream waits
     for an event recorded on the current stream when all_reduce(async_op=True) is called) reads the bucket's FINAL values.  Checked
     without a second GPU: the callback is replaced by exactly that ordering -- event on the compute stream, side stream waits for
@@ -160,6 +163,8 @@ def test_bucket_callback_fires_after_the_last_writer():
 
     cb = L.BUCKET_FN(on_bucket)
     L.check(L.lib.aclgan_set_grad_buckets(tr._ctx, BUCKET, cb, None), "set_grad_buckets")
+    prev_lanes = C.c_int()
+    L.check(L.lib.aclgan_tuning(b"lanes", lanes, C.byref(prev_lanes)), "tuning lanes")
     try:
         for which, grp in (("dis", 1), ("gen", 0)):
             snap[grp] = torch.full_like(tr._grad[grp], float("nan"))
@@ -173,6 +178,7 @@ def test_bucket_callback_fires_after_the_last_writer():
             assert torch.equal(snap[grp], tr._grad[grp]), (which, int((snap[grp] != tr._grad[grp]).sum()))
     finally:
         L.lib.aclgan_set_grad_buckets(tr._ctx, 0, C.cast(None, L.BUCKET_FN), None)
+        L.lib.aclgan_tuning(b"lanes", prev_lanes.value, None)
 
 
 def _shard_trainers(cfg, nets, n):
