@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay each update from a captured HIP graph (launch-bound regimes: small batches / images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-floor", action="store_true", help="skip the 64x64 B=1 launch-bound probe (keeps kernel traces clean)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (the other single-GPU shapes of BASELINE.json, 5 steps each, after the timed region)")
+    ap.add_argument("--lanes", type=int, default=None, help="streams the independent branches of an update are spread over (default: the library's, ACLGAN_LANES or 2; 1 = one queue)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -321,6 +323,15 @@ def main():
     import aclgan_amd  # noqa: F401  (raises if libaclgan_hip.so is missing)
     from aclgan_amd import _lib as L
     from aclgan_amd.trainer import aclgan_Trainer
+    import ctypes as C
+    if args.lanes is not None:
+        L.check(L.lib.aclgan_tuning(b"lanes", args.lanes, None), "tuning lanes")
+
+    def tuning_value(key):      # (read a switch: set it to itself)
+        prev = C.c_int()
+        L.check(L.lib.aclgan_tuning(key, 0, C.byref(prev)), "tuning")
+        L.check(L.lib.aclgan_tuning(key, prev.value, None), "tuning")
+        return prev.value
 
     cfg["display_size"] = 1
     if os.environ.get("ACLGAN_BENCH_TEST_WIDTH"):      # test hook (tests/test_gpu_ddp.py): the control flow of N ranks sharing one GPU over gloo, with
@@ -470,6 +481,46 @@ def main():
         except Exception as e:      # informational only
             log("small-batch probe failed: %r" % (e,))
 
+    # the other single-GPU shapes BASELINE.json names (configs[3] 512x512 fp32 B=4; the per-GPU shapes of the two 8-GPU rows: configs[2]
+    # 256x256 bf16 B=8, configs[4] 256x256 fp16 B=32), 2 warm-up + 5 timed steps each, AFTER the timed region of the headline workload and only
+    # when the run IS the headline workload: so that the driver's own bench file carries them (they are not `value`)
+    other_configs = None
+    headline = (world == 1 and cfg_name == "male2female" and args.dtype == "fp32" and S == 256 and B == 8 and not args.deterministic and not args.graph
+                and not os.environ.get("ACLGAN_BENCH_TEST_WIDTH"))
+    if headline and not args.no_other_configs and os.environ.get("ACLGAN_BENCH_OTHER", "1") != "0":
+        other_configs = []
+        tr._ws = None; tr._ws_shape = None      # (the headline trainer is not stepped again: give its arena back before the larger shapes allocate theirs)
+        torch.cuda.empty_cache()
+        for (yaml_name, odt, oS, oB, label) in (("glasses_removal", "fp32", 512, 4, "configs[3]: glasses-removal 512x512 fp32, batch=4, 1 GPU"),
+                                                ("selfie2anime", "bf16", 256, 8, "configs[2] per-GPU shape: selfie2anime 256x256 bf16, batch=8 (global 64 over 8 GPUs)"),
+                                                ("male2female", "fp16", 256, 32, "configs[4] per-GPU shape: male2female 256x256 fp16 MFMA + loss scaling, batch=32 (global 256 over 8 GPUs)")):
+            try:
+                ocfg = load_config(os.path.join(ROOT, "configs", yaml_name + ".yaml"))
+                ocfg["display_size"] = 1
+                otr = aclgan_Trainer(ocfg, device="cuda:%d" % local_rank, compute_dtype=odt)
+                go = torch.Generator().manual_seed(11)
+                oa = (torch.rand(oB, 3, oS, oS, generator=go) * 2 - 1).cuda(); ob = (torch.rand(oB, 3, oS, oS, generator=go) * 2 - 1).cuda()
+                oz = [torch.randn(oB, ocfg["gen"]["style_dim"], 1, 1, generator=go) for _ in range(3)]
+                n_o = 5
+                for i in range(2 + n_o):
+                    if i == 2:
+                        torch.cuda.synchronize(); to0 = time.perf_counter(); lo0 = L.lib.aclgan_launch_count()
+                    otr.dis_update(oa, ob, ocfg, z=oz); otr.gen_update(oa, ob, ocfg, z=oz); otr.update_learning_rate()
+                torch.cuda.synchronize()
+                oms = (time.perf_counter() - to0) * 1e3 / n_o
+                _, oexec = flops_per_image(oS, odt)
+                other_configs.append({"workload": label, "config_file": "configs/%s.yaml" % yaml_name, "dtype": odt, "size": oS, "batch": oB, "steps": n_o, "warmup": 2,
+                                      "ms_per_step": round(oms, 3), "images_per_s": round(oB / oms * 1e3, 2),
+                                      "frac": round(oexec * oB / (oms / 1e3) / PEAK[odt], 4), "peak_TFLOPs": PEAK[odt],
+                                      "kernel_launches_per_step": round((L.lib.aclgan_launch_count() - lo0) / float(n_o), 1),
+                                      "losses_finite": bool(torch.isfinite(otr.loss_gen_total).item() and torch.isfinite(otr.loss_dis_total).item())})
+                del otr, oa, ob
+                torch.cuda.empty_cache()
+            except Exception as e:      # informational only: never fatal for the headline number
+                other_configs.append({"workload": label, "error": repr(e)[:300]})
+                log("other-config probe %s failed: %r" % (label, e))
+        log("other configs done")
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
@@ -480,7 +531,6 @@ def main():
         name = cfg_name if (args.config or args.dtype == "fp32") else {"bf16": "selfie2anime (male2female architecture)", "fp16": "male2female"}[args.dtype]
         # memory side of the step: algorithmic bytes from a dry run of the scheduler (every operator's inputs read once, outputs written
         # once), measured bytes from the committed PMC passes
-        import ctypes as C
         alg_bytes = 0.0
         for which in (0, 1):
             v = C.c_double()
@@ -513,7 +563,12 @@ def main():
                        "kernel_launches_per_step": round(launches_per_step, 1),
                        "launch_bound_floor_ms_per_step": None if launch_floor_ms is None else round(launch_floor_ms, 2),
                        "reference_cadence_D1_G2_images_per_s": round(world * B / ((t_dis + 0.5 * t_gen) / 1e3), 2),
-                       "small_batch": small_batch, "rccl": rccl_info},
+                       "small_batch": small_batch, "other_configs": other_configs,
+                       # scheduler switches of this run (csrc/engine.hip): branches of an update on `lanes` HIP streams; in a data-parallel run the
+                       # gradient buckets are handed to RCCL from lane 0 = the caller's stream AFTER it has joined every lane and the
+                       # parameter-gradient stream
+                       "lanes": tuning_value(b"lanes"), "batched_filter_transforms": bool(tuning_value(b"u_batch")),
+                       "rccl": rccl_info},
             # frac = what the MFMA pipes really issue (EXECUTED FLOPs: Winograd F(4x4,3x3) runs the 3x3 convolutions with 1/4 of the
             # direct-convolution MACs, the sub-pixel path the upsample+5x5 layers with 9/25) over the dense matrix peak: a hardware
             # fraction, never above 1.  algorithmic_* = the SURVEY 8d contract figure (direct-convolution FLOPs of the step): it can
