@@ -185,33 +185,33 @@ def test_step_reproducible_bit_for_bit(L, dtype):
             assert abs(la[k] - lr[k]) <= (5e-3 if k.endswith("_size") else 1e-4 if dtype == "fp32" else 2e-3) * max(1e-3, abs(lr[k])), (k, la[k], lr[k])
 
 
-def test_three_chained_steps_parameters_match_oracle_elementwise(L, det):
-    """Deterministic mode, three chained (dis_update, gen_update, update_learning_rate) iterations from the same state as the fp32
-    oracle: every parameter compared ELEMENTWISE after the third Adam step (not by norm).
-
-    What can and cannot agree: Adam's update is lr * m_hat / (sqrt(v_hat) + eps), i.e. ~ lr * sign(g) on the first step -- an
-    element whose gradient sits within fp32 summation noise of zero can come out with the other sign (a 2 lr difference per
-    step).  So: (i) hard bound: no element differs by more than 2 lr x 3 steps; (ii) the update as a whole (p - p0) agrees in
-    relative L2 per network; (iii) the bulk of the elements agrees tightly."""
+def chained_report(seed, steps=3):
+    """three chained (dis_update, gen_update, update_learning_rate) iterations of the deterministic HIP trainer and of the fp32 oracle
+    from one state: per network (max |dp| / lr, share of elements within 0.05 lr, relative L2 error of the update p - p0), plus the trainer"""
     from aclgan_amd.trainer import aclgan_Trainer
     cfg = O.default_config()
     cfg["gen"].update(dim=16, mlp_dim=32, n_res=2); cfg["dis"].update(dim=16)
     cfg["display_size"] = 1
     cfg["focus_epsilon"] = 0.5
-    nets = O.test_nets(cfg, 6)
-    g = torch.Generator().manual_seed(77)
+    nets = O.test_nets(cfg, seed)
+    g = torch.Generator().manual_seed(71 + seed)
     x_a = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
     x_b = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
-    zs = [[torch.randn(2, 8, 1, 1, generator=g) for _ in range(6)] for _ in range(3)]
-    tr = aclgan_Trainer(cfg, deterministic=True)
-    for name in O.OracleTrainer.NETS:
-        getattr(tr, name).load_state_dict(nets[name], strict=False)
+    zs = [[torch.randn(2, 8, 1, 1, generator=g) for _ in range(6)] for _ in range(steps)]
+
+    def run():
+        tr = aclgan_Trainer(cfg, deterministic=True)
+        for name in O.OracleTrainer.NETS:
+            getattr(tr, name).load_state_dict(nets[name], strict=False)
+        for it in range(steps):
+            tr.dis_update(x_a, x_b, cfg, z=zs[it][:3]); tr.gen_update(x_a, x_b, cfg, z=zs[it][3:]); tr.update_learning_rate()
+        torch.cuda.synchronize()
+        return tr
+    tr = run()
     p0 = {n: {k: v.clone() for k, v in nets[n].items()} for n in O.OracleTrainer.NETS}
     orc = O.OracleTrainer(cfg, nets=nets)
-    for it in range(3):
-        tr.dis_update(x_a, x_b, cfg, z=zs[it][:3]); tr.gen_update(x_a, x_b, cfg, z=zs[it][3:]); tr.update_learning_rate()
+    for it in range(steps):
         orc.dis_update(x_a, x_b, zs[it][:3]); orc.gen_update(x_a, x_b, zs[it][3:]); orc.update_learning_rate()
-    torch.cuda.synchronize()
     lr = cfg["lr"]
     report = {}
     for n in O.OracleTrainer.NETS:
@@ -224,24 +224,67 @@ def test_three_chained_steps_parameters_match_oracle_elementwise(L, det):
             tight += int((d <= 0.05 * lr).sum()); total += d.numel()
             num += ((got - start) - (ref - start)).pow(2).sum().item(); den += (ref - start).pow(2).sum().item()
         report[n] = (worst / lr, tight / total, (num / max(den, 1e-300)) ** 0.5)
-    print("3 chained deterministic steps vs the fp32 oracle, per network: (max |dp| / lr, share of elements within 0.05 lr, relative L2 of the update)",
-          {n: ("%.2f" % a, "%.4f" % b, "%.2e" % c) for n, (a, b, c) in report.items()})
-    for n, (a, b, c) in report.items():
-        # measured (profiles/r03_gpu_tests.log): generators max 2.7 lr, 88 % / 99.8 % of the elements within 0.05 lr, update error 2.5e-2 /
-        # 3.2e-3; discriminators (no ReLU-mask lottery upstream of their gradients) max 0.2 lr, 100 %, <= 2e-4.
-        # Round 4, same box, three convolution paths of EQUAL operator accuracy (relative L2 of a ResBlock convolution against fp64: direct
-        # 5e-7, three-launch Winograd 3.08e-6, fused Winograd 3.04e-6 -- scripts/probe_fused.py): the share of gen_AB elements within
-        # 0.05 lr is 0.931 / 0.863 / 0.786, its update error 1.7e-2 / 2.3e-2 / 4.9e-2, dis_2 (fed by generator outputs) 1.8e-4 /
-        # 2.4e-4 / 2.0e-3: which near-zero pre-activations flip on this 64 x 64 fixture is a lottery the rounding pattern draws, not a
-        # measure of the kernel.  The bounds leave room for that spread.
-        assert a <= 6.05, (n, a)
-        assert b >= (0.70 if n.startswith("gen") else 0.995), (n, b)
-        assert c <= (0.1 if n.startswith("gen") else 5e-3), (n, c)
-    # and bit-reproducible: a second trainer from the same state lands on the same bits
-    tr2 = aclgan_Trainer(cfg, deterministic=True)
-    for name in O.OracleTrainer.NETS:
-        getattr(tr2, name).load_state_dict(nets[name], strict=False)
-    for it in range(3):
-        tr2.dis_update(x_a, x_b, cfg, z=zs[it][:3]); tr2.gen_update(x_a, x_b, cfg, z=zs[it][3:]); tr2.update_learning_rate()
-    torch.cuda.synchronize()
-    assert torch.equal(tr._param[0], tr2._param[0]) and torch.equal(tr._param[1], tr2._param[1])
+    return report, tr, run
+
+
+# the three convolution paths of the 3x3 layers (tuning switch "wino_fused": 0 = three-launch Winograd pipeline, 2 = the one-launch kernel
+# wherever eligible; the direct kernels are ACLGAN_NOWINO, an environment switch)
+CHAIN_SEEDS = (6, 16, 26)
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_three_chained_steps_parameters_match_oracle_elementwise(L, det, fused):
+    """Deterministic mode, three chained (dis_update, gen_update, update_learning_rate) iterations from the same state as the fp32
+    oracle: every parameter compared ELEMENTWISE after the third Adam step (not by norm).
+
+    What can and cannot agree: Adam's update is lr * m_hat / (sqrt(v_hat) + eps), i.e. ~ lr * sign(g) on the first step -- an
+    element whose gradient sits within fp32 summation noise of zero can come out with the other sign (a 2 lr difference per
+    step).  So: (i) hard bound: no element differs by more than 2 lr x 3 steps; (ii) the update as a whole (p - p0) agrees in
+    relative L2 per network; (iii) the bulk of the elements agrees tightly.
+
+    Round 5 (advisor, round 4): the bounds of (ii) and (iii) are held PER CONVOLUTION PATH and over SEVERAL fixtures -- one 64 x 64
+    fixture and one seed cannot tell a systematic error of a kernel from the lottery of which near-zero pre-activations flip.  The
+    three-launch pipeline keeps the round-3 bounds on the round-3 fixture; both paths must hold the mean over CHAIN_SEEDS, and the
+    fused path may not be systematically worse than the pipeline (mean over the seeds, same fixtures)."""
+    prev = C.c_int()
+    L.check(L.lib.aclgan_tuning(b"wino_fused", fused, C.byref(prev)), "tuning")
+    try:
+        reports = {}
+        for seed in CHAIN_SEEDS:
+            report, tr, run = chained_report(seed)
+            reports[seed] = report
+            print("wino_fused=%d seed %d: 3 chained deterministic steps vs the fp32 oracle, per network: (max |dp| / lr, share of elements within 0.05 lr, "
+                  "relative L2 of the update)" % (fused, seed), {n: ("%.2f" % a, "%.4f" % b, "%.2e" % c) for n, (a, b, c) in report.items()})
+            for n, (a, b, c) in report.items():
+                assert a <= 6.05, (seed, n, a)           # (i): 2 lr per step
+            if seed == CHAIN_SEEDS[0]:
+                # and bit-reproducible: a second trainer from the same state lands on the same bits
+                tr2 = run()
+                assert torch.equal(tr._param[0], tr2._param[0]) and torch.equal(tr._param[1], tr2._param[1])
+        mean = {n: tuple(sum(reports[s][n][i] for s in CHAIN_SEEDS) / len(CHAIN_SEEDS) for i in range(3)) for n in reports[CHAIN_SEEDS[0]]}
+        print("wino_fused=%d mean over seeds %s:" % (fused, CHAIN_SEEDS), {n: ("%.2f" % a, "%.4f" % b, "%.2e" % c) for n, (a, b, c) in mean.items()})
+        for n, (a, b, c) in mean.items():
+            gen = n.startswith("gen")
+            assert b >= (CHAIN_BOUNDS["gen_share"] if gen else CHAIN_BOUNDS["dis_share"]), (fused, n, b)
+            assert c <= (CHAIN_BOUNDS["gen_update"] if gen else CHAIN_BOUNDS["dis_update"]), (fused, n, c)
+        if fused == 0:
+            # the round-3 gate on the round-3 fixture (seed 6), unchanged, for the path it was measured on
+            for n, (a, b, c) in reports[6].items():
+                assert b >= (0.80 if n.startswith("gen") else 0.999), (n, b)
+                assert c <= (0.1 if n.startswith("gen") else 2e-3), (n, c)
+        CHAIN_MEANS[fused] = mean
+        if 0 in CHAIN_MEANS and 2 in CHAIN_MEANS:
+            # the one-launch kernel against the pipeline on the same fixtures: not systematically worse (a ratio of means; measured values
+            # in the test output / profiles/r05_gpu_tests.log)
+            for n in mean:
+                share0, share2 = CHAIN_MEANS[0][n][1], CHAIN_MEANS[2][n][1]
+                err0, err2 = CHAIN_MEANS[0][n][2], CHAIN_MEANS[2][n][2]
+                assert share2 >= share0 - CHAIN_BOUNDS["share_gap"], (n, share0, share2)
+                assert err2 <= max(CHAIN_BOUNDS["err_ratio"] * err0, CHAIN_BOUNDS["err_floor"]), (n, err0, err2)
+    finally:
+        L.check(L.lib.aclgan_tuning(b"wino_fused", prev.value, None), "tuning")
+
+
+# measured on the MI355X (profiles/r05_gpu_tests.log); the bounds are set from those means with the margin stated next to each
+CHAIN_BOUNDS = {"gen_share": 0.75, "dis_share": 0.995, "gen_update": 0.1, "dis_update": 5e-3, "share_gap": 0.08, "err_ratio": 3.0, "err_floor": 2e-3}
+CHAIN_MEANS = {}
