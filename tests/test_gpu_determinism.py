@@ -285,6 +285,10 @@ def test_three_chained_steps_parameters_match_oracle_elementwise(L, det, fused):
         L.check(L.lib.aclgan_tuning(b"wino_fused", prev.value, None), "tuning")
 
 
-# measured on the MI355X (profiles/r05_gpu_tests.log); the bounds are set from those means with the margin stated next to each
-CHAIN_BOUNDS = {"gen_share": 0.75, "dis_share": 0.995, "gen_update": 0.1, "dis_update": 5e-3, "share_gap": 0.08, "err_ratio": 3.0, "err_floor": 2e-3}
+# Measured on the MI355X (round 5, profiles/r05_experiments.md section 1): mean over the three fixtures, pipeline / fused --
+#   share within 0.05 lr: gen_AB 0.881 / 0.860, gen_BA 0.930 / 0.992, discriminators >= 0.9998 / 0.9998;
+#   update error: gen_AB 2.5e-2 / 3.3e-2, gen_BA 1.6e-2 / 5.8e-3, dis_2 7.3e-4 / 1.2e-3, dis_A / dis_B <= 1e-4.
+# Per fixture the two paths trade places (seed 6: gen_AB 0.863 / 0.924; seed 26: 0.862 / 0.742): which near-zero pre-activations flip is
+# drawn by the rounding pattern, not by the path.  Bounds = those means with ~7 % (shares) / ~2x (errors) of room.
+CHAIN_BOUNDS = {"gen_share": 0.80, "dis_share": 0.999, "gen_update": 0.06, "dis_update": 2.5e-3, "share_gap": 0.06, "err_ratio": 2.0, "err_floor": 2e-3}
 CHAIN_MEANS = {}
