@@ -25,13 +25,15 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 // scheduler switches (common.h)
-static std::atomic<int> g_lanes{-1}, g_u_batch{-1};
+static std::atomic<int> g_lanes{-1}, g_u_batch{-1}, g_norm_mask{-1};
 static std::atomic<long long> g_tuning_epoch{0};
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 int lanes_setting() { int v = g_lanes.load(); if (v < 0) { v = std::max(1, std::min(4, env_int("ACLGAN_LANES", 2))); g_lanes.store(v); } return v; }
 int set_lanes(int v) { const int old = lanes_setting(); g_lanes.store(std::max(1, std::min(4, v))); return old; }
 int u_batch_setting() { int v = g_u_batch.load(); if (v < 0) { v = env_int("ACLGAN_U_BATCH", 1) ? 1 : 0; g_u_batch.store(v); } return v; }
 int set_u_batch(int v) { const int old = u_batch_setting(); g_u_batch.store(v ? 1 : 0); return old; }
+int norm_mask_setting() { int v = g_norm_mask.load(); if (v < 0) { v = env_int("ACLGAN_NORM_MASK", 1) ? 1 : 0; g_norm_mask.store(v); } return v; }
+int set_norm_mask(int v) { const int old = norm_mask_setting(); g_norm_mask.store(v ? 1 : 0); return old; }
 static std::atomic<int> g_fault_at{-1};
 int fault_at_setting() { return g_fault_at.load(); }
 int set_fault_at(int v) { return g_fault_at.exchange(v); }
@@ -274,6 +276,7 @@ int aclgan_tuning(const char* key, int value, int* previous) {
     else if (!strcmp(key, "dgrad16s_direct")) old = set_dgrad16s_direct(value);
     else if (!strcmp(key, "lanes")) old = set_lanes(value);
     else if (!strcmp(key, "u_batch")) old = set_u_batch(value);
+    else if (!strcmp(key, "norm_mask")) old = set_norm_mask(value);
     else if (!strcmp(key, "fault_at")) old = set_fault_at(value);
     else { set_error("aclgan_tuning: unknown key '%s'", key); return ACLGAN_EINVAL; }
     bump_tuning_epoch();

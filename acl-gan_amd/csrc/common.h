@@ -46,6 +46,9 @@ int lanes_setting();
 int set_lanes(int v);            // returns the previous value
 int u_batch_setting();
 int set_u_batch(int v);
+//   norm_mask (ACLGAN_NORM_MASK, default 1): the norm backward recomputes ReLU masks from x and the forward's coefficients instead of reading y
+int norm_mask_setting();
+int set_norm_mask(int v);
 //   fault_at (test hook, default -1 = off): the backward replay fails with ACLGAN_EHIP after its fault_at-th closure has been enqueued --
 //   the error path (lanes and side stream drained before the caller is told) is testable without breaking the GPU
 int fault_at_setting();
@@ -209,12 +212,15 @@ size_t norm_scratch_bytes(int B, int HW, int C);
 struct NormST { int x = 0, y = 0, res = 0, dy = 0, dx = 0, dres = 0; };
 int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float* w, const float* b, int w_stride,
              const void* residual, void* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats = nullptr,
-             int stats_chunk = 0, const NormST* sto = nullptr);
+             int stats_chunk = 0, const NormST* sto = nullptr, float* ss_out = nullptr);
+// ss_out (norm_fwd, optional, 2 B C floats) / ss (norm_bwd): the fused coefficients (scale | shift) of y = act(x * scale + shift).  Kept by
+// the caller from the forward to the backward, norm_bwd recovers a ReLU / LeakyReLU mask as the sign of the same fmaf and does not read y.
 // sbc_out (optional, LayerNorm only, [B][C][2] floats): receives the per-sample totals (sum g, sum g*xhat) per channel INSTEAD of the
 // gamma / beta gradients being added here -- the caller adds them later with norm_bwd_ln_params (on its parameter-gradient stream)
 int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy,
              const float* w, int w_stride, const float* mean, const float* rstd, void* dx, float* dw, float* db,
-             void* dres, int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto = nullptr, float* sbc_out = nullptr);
+             void* dres, int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto = nullptr, float* sbc_out = nullptr,
+             const float* ss = nullptr);
 // dgamma[c] += sum_b sbc[b][c][1], dbeta[c] += sum_b sbc[b][c][0], samples added in index order
 int norm_bwd_ln_params(const float* sbc, int B, int C, float* dgamma, float* dbeta, hipStream_t st);
 

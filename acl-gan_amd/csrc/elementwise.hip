@@ -224,7 +224,7 @@ size_t norm_scratch_bytes(int B, int HW, int C) {
 // (conv_fwd_stats_chunk) -- and the statistics pass over x is skipped
 int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float* w, const float* b, int w_stride,
              const void* residual, void* y, float* mean, float* rstd, void* scratch, hipStream_t st, const float* stats, int stats_chunk,
-             const NormST* sto) {
+             const NormST* sto, float* ss_out) {
     const NormST sd = sto ? *sto : NormST();
     ACL_REQUIRE(pow2(C) && C >= 4 && C <= 1024, "norm: C=%d must be a power of two in [4,1024]", C);
     ACL_REQUIRE(kind == ACLGAN_NORM_IN || kind == ACLGAN_NORM_ADAIN || kind == ACLGAN_NORM_LN, "norm: bad kind %d", kind);
@@ -233,7 +233,9 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float
     const int own_chunk = norm_chunk_pixels(B, HW);
     const int chunk = stats ? stats_chunk : own_chunk, nchunks = cdiv(HW, chunk);
     float2* part = stats ? (float2*)stats : (float2*)scratch;
-    float* scale = (float*)((float2*)scratch + (size_t)B * cdiv(HW, own_chunk) * C);
+    // the fused coefficients y = act(x * scale + shift): in the scratch, or -- ss_out, 2 B C floats -- in a buffer the caller keeps for
+    // norm_bwd, which then recomputes the activation mask from x with the very same fmaf instead of reading y back
+    float* scale = ss_out ? ss_out : (float*)((float2*)scratch + (size_t)B * cdiv(HW, own_chunk) * C);
     float* shift = scale + (size_t)B * C;
     if (!stats) {
         hipLaunchKernelGGL(norm_stats_kernel, dim3(nchunks, B), dim3(256), 0, st, x, sd.x, part, HW, C, chunk, nchunks);
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __rest
                                                               const void* __restrict__ dy, NormST st, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int per_channel_stats,
                                                               float2* __restrict__ part, int HW, int C, int chunk,
-                                                              int nchunks, int act) {
+                                                              int nchunks, int act, const float* __restrict__ msc, const float* __restrict__ msh) {
     const int C4 = C >> 2;
     const int b = blockIdx.y, ch = blockIdx.x;
     const int p0 = ch * chunk, p1 = min(HW, p0 + chunk);
@@ -286,11 +288,18 @@ __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __rest
         mu = make_float4(m, m, m, m); rs = make_float4(r, r, r, r);
     }
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    float4 ksc = make_float4(0, 0, 0, 0), ksh = ksc;
+    if (msc) { ksc = *reinterpret_cast<const float4*>(msc + b * C + cg * 4); ksh = *reinterpret_cast<const float4*>(msh + b * C + cg * 4); }
     for (int p = p0 + pl; p < p1; p += PL) {
         const int64_t i = base + (int64_t)p * C4 + cg;
         const st_f32x4 xv = st_ld4(x, i, st.x), gv = st_ld4(dy, i, st.dy);
         st_f32x4 yv = {1.f, 1.f, 1.f, 1.f};
-        if (act != ACLGAN_ACT_NONE) yv = st_ld4(y, i, st.y);   // act-less norms (2nd norm of every ResBlock): y is not needed, skip its HBM read
+        // act-less norms (2nd norm of every ResBlock): y is not needed.  ReLU / LeakyReLU with the forward's coefficients at hand (msc): the mask
+        // is the sign of the forward's own fmaf(x, scale, shift) -- recomputed, the read of y is saved
+        if (act != ACLGAN_ACT_NONE) {
+            if (msc) { yv.x = fmaf(xv.x, ksc.x, ksh.x); yv.y = fmaf(xv.y, ksc.y, ksh.y); yv.z = fmaf(xv.z, ksc.z, ksh.z); yv.w = fmaf(xv.w, ksc.w, ksh.w); }
+            else yv = st_ld4(y, i, st.y);
+        }
         const float g0 = gv.x * act_grad(yv.x, act), g1 = gv.y * act_grad(yv.y, act);
         const float g2 = gv.z * act_grad(yv.z, act), g3 = gv.w * act_grad(yv.w, act);
         s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
@@ -413,7 +422,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restr
                                                              const float* __restrict__ cA, const float* __restrict__ cB,
                                                              const float* __restrict__ cC, void* __restrict__ dx,
                                                              void* __restrict__ dres, int dres_acc, int HW, int C, int act,
-                                                             int64_t total4) {
+                                                             int64_t total4, const float* __restrict__ msc, const float* __restrict__ msh) {
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int cg = (int)(i % C4);
@@ -431,7 +440,12 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restr
         const float4 kc = *reinterpret_cast<const float4*>(cC + o);
         const st_f32x4 xv = st_ld4(x, i, st.x), gv = st_ld4(dy, i, st.dy);
         st_f32x4 yv = {1.f, 1.f, 1.f, 1.f};
-        if (act != ACLGAN_ACT_NONE) yv = st_ld4(y, i, st.y);
+        if (act != ACLGAN_ACT_NONE) {
+            if (msc) {
+                const float4 ksc = *reinterpret_cast<const float4*>(msc + o), ksh = *reinterpret_cast<const float4*>(msh + o);
+                yv.x = fmaf(xv.x, ksc.x, ksh.x); yv.y = fmaf(xv.y, ksc.y, ksh.y); yv.z = fmaf(xv.z, ksc.z, ksh.z); yv.w = fmaf(xv.w, ksc.w, ksh.w);
+            } else yv = st_ld4(y, i, st.y);
+        }
         st_f32x4 g;
         g.x = gv.x * act_grad(yv.x, act); g.y = gv.y * act_grad(yv.y, act);
         g.z = gv.z * act_grad(yv.z, act); g.w = gv.w * act_grad(yv.w, act);
@@ -450,8 +464,11 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restr
 
 int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void* y, const void* dy, const float* w,
              int w_stride, const float* mean, const float* rstd, void* dx, float* dw, float* db, void* dres,
-             int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto, float* sbc_out) {
+             int dres_accumulate, void* scratch, hipStream_t st, const NormST* sto, float* sbc_out, const float* ss) {
     const NormST sd = sto ? *sto : NormST();
+    // ss (optional): norm_fwd's ss_out of the same layer -- only a sign-based activation can be recovered from the pre-activation
+    const float* msc = (ss && (act == ACLGAN_ACT_RELU || act == ACLGAN_ACT_LRELU)) ? ss : nullptr;
+    const float* msh = msc ? msc + (size_t)B * C : nullptr;
     ACL_REQUIRE(pow2(C) && C >= 4 && C <= 1024, "norm: C=%d must be a power of two in [4,1024]", C);
     const int chunk = norm_chunk_pixels(B, HW), nchunks = cdiv(HW, chunk);
     float2* part = (float2*)scratch;
@@ -460,7 +477,7 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
     float* cC = cB + (size_t)B * C;
     const int pcs = kind != ACLGAN_NORM_LN;
     hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(nchunks, B), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, part, HW, C, chunk,
-                       nchunks, act);
+                       nchunks, act, msc, msh);
     ACL_CHECK_LAUNCH("norm_bwd_reduce_kernel");
     if (kind == ACLGAN_NORM_LN) {
         ACL_REQUIRE(w, "LN backward needs gamma");
@@ -480,7 +497,7 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
     const int64_t total4 = (int64_t)B * HW * C / 4;
     const int grid = (int)std::min<int64_t>(cdiv64(total4, 256), 8192);
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, cA, cB, cC, dx, dres, dres_accumulate,
-                       HW, C, act, total4);
+                       HW, C, act, total4, msc, msh);
     ACL_CHECK_LAUNCH("norm_bwd_apply_kernel");
     return ACLGAN_OK;
 }

@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 #include <tuple>
+#include <mutex>
 #include <algorithm>
 #include <cstring>
 #include <cstdio>
@@ -108,6 +109,40 @@ struct Roctx {
         }
     }
     static Roctx& get() { static Roctx r; return r; }
+};
+}  // namespace aclgan
+
+// Streams of the lanes and the parameter-gradient stream: ONE set per device for the whole process, shared by every context (created on first
+// use, never destroyed).  HIP multiplexes streams onto a few hardware queues in creation order (GPU_MAX_HW_QUEUES, default 4): with a set per
+// context, the second trainer of a process (bench.py's small-batch probe, a test suite) got streams that SHARE a hardware queue with the
+// caller's stream, and its lanes serialised -- measured as a 5 ms spread of the same B=3 step between otherwise identical runs
+// (profiles/r05_experiments.md section 2).  Contexts are used one update at a time per thread; two threads stepping two contexts at once
+// would interleave their work on these streams (ordered by their own events: still correct).
+namespace aclgan {
+struct StreamPool {
+    static const int N = 4;      // [0] = parameter-gradient (side) stream, [1..3] = lanes 1..3
+    hipStream_t s[N] = {nullptr, nullptr, nullptr, nullptr};
+    static StreamPool& of_device() {
+        static StreamPool pools[16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return pools[(dev >= 0 && dev < 16) ? dev : 0];
+    }
+    int get(int i, hipStream_t* out) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!s[i]) {
+            hipError_t e = hipSuccess;
+            static int prio = -1;      // ACLGAN_SIDE_PRIO=1: the parameter-gradient stream at the highest priority the device offers (measured neutral, round 4)
+            if (prio < 0) { const char* pe = getenv("ACLGAN_SIDE_PRIO"); prio = pe ? atoi(pe) : 0; }
+            int lo = 0, hi = 0;
+            if (i == 0 && prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) e = hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, prio > 0 ? hi : lo);
+            else e = hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking);
+            if (e != hipSuccess) { s[i] = nullptr; return hip_fail(e, "stream pool"); }
+        }
+        *out = s[i];
+        return ACLGAN_OK;
+    }
 };
 }  // namespace aclgan
 
@@ -243,17 +278,13 @@ struct aclgan_ctx {
     int side_fork() {       // the side stream may start once everything enqueued on the current lane so far is done
         if (dry) return ACLGAN_OK;
         if (!st2) {
-            // ACLGAN_SIDE_PRIO=1: the side stream at the highest priority the device offers (its kernels are small and fill the tails of the
-            // main stream's launches; measured in round 4, see profiles/r04_experiments.md)
-            static int prio = -1;
-            if (prio < 0) { const char* pe = getenv("ACLGAN_SIDE_PRIO"); prio = pe ? atoi(pe) : 0; }
-            int lo = 0, hi = 0;
-            hipError_t e = hipSuccess;
-            if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) e = hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, prio > 0 ? hi : lo);
-            else e = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+            int rc = aclgan::StreamPool::of_device().get(0, &st2);
+            if (rc) return rc;
+        }
+        if (!ev_fork) {
+            hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
-            if (e != hipSuccess) return aclgan::hip_fail(e, "side stream");
+            if (e != hipSuccess) return aclgan::hip_fail(e, "side stream events");
         }
         hipError_t e = hipEventRecord(ev_fork, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(st2, ev_fork, 0);
@@ -304,8 +335,10 @@ struct aclgan_ctx {
         for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
         ev_next = 0;
         if (dry) return ACLGAN_OK;
+        // (parameter-gradient stream first, then the lanes: with the caller's stream that is one hardware queue each up to 3 lanes)
+        if (side_enabled() && !st2) { int rc = aclgan::StreamPool::of_device().get(0, &st2); if (rc) return rc; }
         for (int l = 1; l < nlanes; ++l)
-            if (!lane_st[l]) { hipError_t e = hipStreamCreateWithFlags(&lane_st[l], hipStreamNonBlocking); if (e != hipSuccess) return aclgan::hip_fail(e, "lane stream"); }
+            if (!lane_st[l]) { int rc = aclgan::StreamPool::of_device().get(l, &lane_st[l]); if (rc) return rc; }
         return ACLGAN_OK;
     }
     // checkpoint of lane l: everything enqueued on it so far
@@ -409,8 +442,7 @@ struct aclgan_ctx {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
-        if (st2) (void)hipStreamDestroy(st2);
-        for (int l = 1; l < MAXL; ++l) if (lane_st[l]) (void)hipStreamDestroy(lane_st[l]);
+        // (the streams belong to the process-wide pool)
     }
     void reset_step() {
         for (Act* a : acts) delete a;
@@ -651,7 +683,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     Act* co = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad, co_st);
     NEED(co->d); if (want_grad) NEED(co->g);
     Act* out = co;
-    float *mean = nullptr, *rstd = nullptr;
+    float *mean = nullptr, *rstd = nullptr, *ss = nullptr;
     const int HW = g.Ho * g.Wo;
     if (has_norm) {
         out = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad, out_st);
@@ -659,6 +691,9 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         const int nstat = ns.kind == ACLGAN_NORM_LN ? g.B : g.B * Co;
         mean = c.allocf(nstat); rstd = c.allocf(nstat);
         NEED(mean); NEED(rstd);
+        // the fused coefficients of the apply stay until the backward: its ReLU mask is then the sign of the same fmaf(x, scale, shift), and
+        // neither backward pass reads y (2 of 6 / 1 of 4 tensor reads of the reduce / apply of every activated norm layer)
+        if (want_grad && (act == ACLGAN_ACT_RELU || act == ACLGAN_ACT_LRELU) && norm_mask_setting()) { ss = c.allocf((int64_t)2 * g.B * Co); NEED(ss); }
         co->gdt = s_bwd ? dt : 0;             // read by this layer's dgrad / wgrad kernels
     } else if (out_st && !co_st) {            // an fp32-only kernel (image-side first layers) feeding 16-bit consumers: one conversion pass
         out = c.new_act(g.B, g.Ho, g.Wo, Co, want_grad, out_st);
@@ -702,7 +737,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     if (has_norm) {
         void* scr = c.alloc(norm_scratch_bytes(g.B, HW, Co));
         NEED(scr);
-        RUN(norm_fwd(ns.kind, act, g.B, HW, Co, co->d, ns.w, ns.b, ns.w_stride, residual ? residual->d : nullptr, out->d, mean, rstd, scr, c.st, stats, schunk, &nst));
+        RUN(norm_fwd(ns.kind, act, g.B, HW, Co, co->d, ns.w, ns.b, ns.w_stride, residual ? residual->d : nullptr, out->d, mean, rstd, scr, c.st, stats, schunk, &nst, ss));
     } else if (out != co) {
         RUN(cast_storage(co->d, co->dt, out->d, out->dt, co->numel(), c.st));
     }
@@ -746,7 +781,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
             if (residual && residual->need_grad) { dres = residual->g; dacc = residual->gw ? 1 : 0; mark_written(residual); }
             NormST bst;
             bst.x = co->dt; bst.y = out->dt; bst.dy = out->gdt; bst.dx = co->gdt; bst.dres = residual ? residual->gdt : 0;
-            RUN(norm_bwd(ns.kind, act, g.B, HW, Co, co->d, out->d, out->g, ns.w, ns.w_stride, mean, rstd, co->g, ns.dw, ns.db, dres, dacc, scr, c.st, &bst, sbc));
+            RUN(norm_bwd(ns.kind, act, g.B, HW, Co, co->d, out->d, out->g, ns.w, ns.w_stride, mean, rstd, co->g, ns.dw, ns.db, dres, dacc, scr, c.st, &bst, sbc, ss));
             c.top = mark;
             dyp = co->g; dy_st = co->gdt;
         } else if (s_bwd && out->gdt == 0) {
@@ -1315,7 +1350,9 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     // Lanes (round 5).  Lane 0 carries the chain everything else waits for: x_a -> gen_AB -> x_B_fake -> gen_BA -> x_A2_fake
     // (trainer.py:103,108,110,125-128); lane 1 the other translation direction and the two reconstructions (trainer.py:104-105,109,111,
     // 113-114), which only meet the chain again in the discriminators.  One lane: the same host order on one queue.
-    const int L0 = 0, L1 = 1;
+    // A third lane takes the reconstruction of x_b (trainer.py:105,114: encode(x_b) -> decode, independent of everything else up to its L1
+    // loss) and the coarser discriminator scales.
+    const int L0 = 0, L1 = 1, L2 = c.nlanes > 2 ? 2 : 1, LS = c.nlanes > 2 ? 2 : 0;
 #define PASS(expr) do { CHK(expr); CHK(c.mark()); } while (0)
     CHK(c.mark());                                                    // (the preamble: inputs, noise, filter transforms)
     CHK(c.set_lane(L0));
@@ -1335,15 +1372,16 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     PASS(blend(c, dA24, xB, xa, &xA2, &pA2, c.new_view(jA, B, B), c.new_view(jP, B, B)));   // trainer.py:128,133
     CHK(c.set_lane(L1));
     PASS(decode(c, BA, true, c2, s2, &rA4)); CHK(zero_grad_of(c, rA4));   // trainer.py:113
+    CHK(c.set_lane(L2));
     PASS(content_encode(c, AB, true, xb, &c4));                      // trainer.py:105
     PASS(style_encode(c, AB, true, xb, &s4));
     PASS(decode(c, AB, true, c4, s4, &rB4)); CHK(zero_grad_of(c, rB4));   // trainer.py:114
     // adversarial terms (trainer.py:136-139); discriminators frozen.  dis_B only needs x_B_fake: it is enqueued first; each pass runs its
     // full-resolution scale on one lane and the coarser scales on the other
-    PASS(dis_lsgan(c, ACLGAN_NET_DIS_B, false, xB, B, {{1.f, 1.f, hp.gan_w, L + ACLGAN_L_GEN_ADV_B}}, L1, L0));
-    PASS(dis_lsgan(c, ACLGAN_NET_DIS_A, false, jA, B, {{1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}, {1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}}, L0, L1));
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_B, false, xB, B, {{1.f, 1.f, hp.gan_w, L + ACLGAN_L_GEN_ADV_B}}, L1, LS));
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_A, false, jA, B, {{1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}, {1.f, 0.5f, hp.gan_w, L + ACLGAN_L_GEN_ADV_A}}, L0, L2));
     PASS(dis_lsgan(c, ACLGAN_NET_DIS_2, false, jP, B, {{1.f, 1.f, hp.gan_cw, L + ACLGAN_L_GEN_ADV_2},     // networks.py:98: pair_A1 -> 1
-                                                        {0.f, 1.f, hp.gan_cw, L + ACLGAN_L_GEN_ADV_2}}, L1, L0));  //                 pair_A2 -> 0
+                                                        {0.f, 1.f, hp.gan_cw, L + ACLGAN_L_GEN_ADV_2}}, L1, LS));  //                 pair_A2 -> 0
     CHK(c.lanes_join());                                              // the loss kernels below read all of it, on lane 0
     // focus losses (trainer.py:145-161)
     const int64_t npix = (int64_t)B * H * W;
@@ -1418,8 +1456,8 @@ static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
         if (e != hipSuccess) return hip_fail(e, "copy real images into the joint discriminator batch");
     }
     // lanes as in gen_update: lane 0 = the chain x_a -> gen_AB -> x_B_fake -> gen_BA -> x_A2_fake, lane 1 = the other direction, then
-    // dis_B (which needs only x_B_fake) next to the second half of the chain
-    const int L0 = 0, L1 = 1;
+    // dis_B (which needs only x_B_fake) next to the second half of the chain; a third lane takes the coarser discriminator scales
+    const int L0 = 0, L1 = 1, L2 = c.nlanes > 2 ? 2 : 1, LS = c.nlanes > 2 ? 2 : 0;
     CHK(c.mark());
     CHK(c.set_lane(L0));
     PASS(content_encode(c, AB, false, xa, &c1));
@@ -1432,14 +1470,14 @@ static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     PASS(decode(c, BA, false, c2, z2, &dA4));
     PASS(blend(c, dA4, xa, xa, &xA, &pA1, c.new_view(jA, 0, B), c.new_view(jP, 0, B)));
     // calc_dis_loss(fake -> 0, real -> 1) (networks.py:60-67; trainer.py:283-286)
-    PASS(dis_lsgan(c, ACLGAN_NET_DIS_B, true, jB, B, {{0.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}, {1.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}}, L1, L1));
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_B, true, jB, B, {{0.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}, {1.f, 1.f, hp.gan_w, L + ACLGAN_L_DIS_B}}, L1, L2));
     CHK(c.set_lane(L0));
     PASS(content_encode(c, BA, false, xB, &c3));
     PASS(decode(c, BA, false, c3, z3, &dA24));
     PASS(blend(c, dA24, xB, xa, &xA2, &pA2, c.new_view(jA, B, B), c.new_view(jP, B, B)));
     PASS(dis_lsgan(c, ACLGAN_NET_DIS_A, true, jA, B, {{0.f, 0.5f, hp.gan_w, L + ACLGAN_L_DIS_A}, {0.f, 0.5f, hp.gan_w, L + ACLGAN_L_DIS_A},
-                                                       {1.f, 1.0f, hp.gan_w, L + ACLGAN_L_DIS_A}}, L0, L1));   // the real branch occurs twice x 0.5
-    PASS(dis_lsgan(c, ACLGAN_NET_DIS_2, true, jP, B, {{0.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}, {1.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}}, L1, L0));
+                                                       {1.f, 1.0f, hp.gan_w, L + ACLGAN_L_DIS_A}}, L0, L2));   // the real branch occurs twice x 0.5
+    PASS(dis_lsgan(c, ACLGAN_NET_DIS_2, true, jP, B, {{0.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}, {1.f, 1.f, hp.gan_cw, L + ACLGAN_L_DIS_2}}, L1, LS));
     CHK(c.lanes_join());
     if (!c.dry) {
         hipLaunchKernelGGL(dis_total_kernel, dim3(1), dim3(1), 0, c.st, L, hp);

@@ -233,19 +233,21 @@ def test_full_size_step_properties_16bit(T, dt):
     assert np.isfinite(float(tr.loss_dis_total))
 
 
-def test_fp16_at_its_per_gpu_batch_32(T):
-    """BASELINE configs[4] at its real per-GPU workload: fp16 MFMA + dynamic loss scaling, 256x256, B = 256 / 8 GPUs = 32
+@pytest.mark.parametrize("dt,B,NS", [("fp16", 32, 4), ("bf16", 8, 2)], ids=["fp16_b32", "bf16_b8"])
+def test_16bit_at_its_per_gpu_batch(T, dt, B, NS):
+    """BASELINE configs[4] / configs[2] at their real per-GPU workloads (round 5: bf16 B = 64 / 8 GPUs = 8 as well -- until now the bf16 build
+    at this shape was only compared with the repo's own fp32 build).
+    fp16 MFMA + dynamic loss scaling, 256x256, B = 256 / 8 GPUs = 32
     (different split-K plans and a ~4x arena compared with the B=8 test above).
       * forward parity against the fp32 ORACLE on a 4-sample subset: every normalisation on the path is per sample, so samples
         0..3 of the B=32 HIP forward must match the oracle run on those four samples alone, within the fp16 bounds stated above;
       * the step's own fused loss kernels at B=32 against a recomputation from the B=32 public-API forward (L1 identity loss,
         the LSGAN generator terms): 1e-4;
       * losses finite, loss scale untouched (no overflow at B=32), the two optimizers stay separate, |first Adam step| <= lr."""
-    dt = "fp16"
     cfg = O.default_config()
     cfg["display_size"] = 1
     nets = O.test_nets(cfg, 0)
-    B, S, NS = 32, 256, 4
+    S = 256
     x_a, x_b, z = _inputs(B, S, 25)
     tr = _make(T, cfg, nets, dt)
     xa = x_a.cuda()
@@ -274,24 +276,29 @@ def test_fp16_at_its_per_gpu_batch_32(T):
         worst[name] = _rel(got[:NS], fw[name])
     for s_, (g_, w_) in enumerate(zip(dA, dAo)):
         worst["dis_A_xA_s%d" % s_] = _rel(g_[:NS], w_)
-    print("fp16 B=32 forward max-abs rel errors vs the fp32 oracle on samples 0..3:", {k: "%.2e" % v for k, v in worst.items()})
+    print("%s B=%d forward max-abs rel errors vs the fp32 oracle on samples 0..%d:" % (dt, B, NS - 1), {k: "%.2e" % v for k, v in worst.items()})
     bad = {k: v for k, v in worst.items() if not v < FTOL[dt]}
     assert not bad, bad
     # ---- the update at B=32 ----
     gen0 = tr._param[0].clone(); dis0 = tr._param[1].clone()
-    assert tr.grad_scale() == 65536.0
+    assert tr.grad_scale() == SCALE[dt]
     tr.gen_update(x_a, x_b, cfg, z=z[3:])
     torch.cuda.synchronize()
     want = {"loss_idt_A": (rec[:, :3] - xa).abs().mean().item(),
             "loss_gen_adv_B": sum(((o - 1) ** 2).mean().item() for o in dB),
             "loss_gen_adv_A": sum(0.5 * ((o[:B] - 1) ** 2).mean().item() + 0.5 * ((o[B:] - 1) ** 2).mean().item() for o in dA),
             "loss_gen_adv_2": sum(((o[:B] - 1) ** 2).mean().item() + (o[B:] ** 2).mean().item() for o in d2)}
+    # (the public-API forward feeds fp32 copies of the 16-bit tensors through different kernels than the step: same values, another summation
+    #  order, and in bf16 a rounding flip is a 2^-9 kick -- hence 2e-3 there; fp16 measured <= 1.5e-5)
+    ltol = 1e-4 if dt == "fp16" else 2e-3
     for n, v in want.items():
         got = float(getattr(tr, n))
-        assert np.isfinite(got) and abs(got - v) <= 1e-4 * max(1e-3, abs(v)), (n, got, v)
-    st = tr.loss_scale_state()
-    assert st["skipped_gen"] == 0 and st["scale"] == 65536.0 and st["clean_updates"] == 1, st
-    assert tr.grad_scale() == 65536.0
+        print("  %s B=%d %s: step %.6f, recomputed from the public-API forward %.6f" % (dt, B, n, got, v))
+        assert np.isfinite(got) and abs(got - v) <= ltol * max(1e-3, abs(v)), (n, got, v)
+    if dt == "fp16":
+        st = tr.loss_scale_state()
+        assert st["skipped_gen"] == 0 and st["scale"] == 65536.0 and st["clean_updates"] == 1, st
+    assert tr.grad_scale() == SCALE[dt]
     assert torch.equal(tr._param[1], dis0)
     d = (tr._param[0] - gen0).abs().max().item()
     assert 0 < d <= 1.01 * cfg["lr"]
@@ -300,7 +307,61 @@ def test_fp16_at_its_per_gpu_batch_32(T):
     torch.cuda.synchronize()
     assert torch.equal(tr._param[0], gen1)
     assert 0 < (tr._param[1] - dis0).abs().max().item() <= 1.01 * cfg["lr"]
-    assert np.isfinite(float(tr.loss_dis_total)) and tr.loss_scale_state()["skipped_dis"] == 0
+    assert np.isfinite(float(tr.loss_dis_total)) and (dt != "fp16" or tr.loss_scale_state()["skipped_dis"] == 0)
+
+
+# measured on the MI355X (profiles/r05_gpu_tests.log): worst relative deviation of loss_gen_total / loss_dis_total from the fp32 HIP run over
+# the 20 iterations; the band is ~2x that
+TRACK_BAND = {"bf16": {"loss_gen_total": 4e-2, "loss_dis_total": 4e-2}, "fp16": {"loss_gen_total": 6e-3, "loss_dis_total": 6e-3}}
+
+
+def test_loss_trajectory_16bit_tracks_fp32(T):
+    """Twenty chained iterations (dis_update, gen_update, update_learning_rate; reduced width, fixed batches and noise, lr x 10 so that the
+    parameters move): the bf16 and fp16 HIP trainers follow the fp32 HIP trainer -- loss_gen_total and loss_dis_total of every iteration
+    within a stated band, no divergence with depth of training (only fp32 had chained-step and loop tests before).  fp16 runs under its
+    dynamic loss scaling and must not skip an update on the way."""
+    cfg = O.default_config()
+    cfg["gen"].update(dim=32, mlp_dim=64, n_res=2); cfg["dis"].update(dim=32)
+    cfg["display_size"] = 1
+    cfg["focus_epsilon"] = 0.5
+    cfg["lr"] = 10 * cfg["lr"]
+    nets = O.test_nets(cfg, 4)
+    NIT = 20
+    batches = [_inputs(2, 64, 100 + i % 3) for i in range(NIT)]          # three batches in rotation, their own noise
+    traj = {}
+    for dt in ("fp32", "bf16", "fp16"):
+        tr = _make(T, cfg, nets, dt)
+        rows = []
+        for it in range(NIT):
+            x_a, x_b, z = batches[it]
+            tr.dis_update(x_a, x_b, cfg, z=z[:3]); tr.gen_update(x_a, x_b, cfg, z=z[3:]); tr.update_learning_rate()
+            rows.append((float(tr.loss_gen_total), float(tr.loss_dis_total)))
+        traj[dt] = rows
+        if dt == "fp16":
+            st = tr.loss_scale_state()
+            assert st["skipped_gen"] == 0 and st["skipped_dis"] == 0, st
+    # the losses must actually move over the run (otherwise "tracks" says nothing)
+    g0, g1 = traj["fp32"][0][0], traj["fp32"][-1][0]
+    d0, d1 = traj["fp32"][0][1], traj["fp32"][-1][1]
+    print("fp32 trajectory: loss_gen_total %.4f -> %.4f, loss_dis_total %.4f -> %.4f" % (g0, g1, d0, d1))
+    assert abs(d1 - d0) > 1e-2 * abs(d0)
+    for dt in ("bf16", "fp16"):
+        worst = {"loss_gen_total": (0.0, -1), "loss_dis_total": (0.0, -1)}
+        for it in range(NIT):
+            for j, name in enumerate(("loss_gen_total", "loss_dis_total")):
+                ref = traj["fp32"][it][j]; got = traj[dt][it][j]
+                assert np.isfinite(got)
+                dev = abs(got - ref) / max(1e-3, abs(ref))
+                if dev > worst[name][0]:
+                    worst[name] = (dev, it)
+        print("%s vs fp32 over %d iterations, worst relative deviation (iteration):" % (dt, NIT), {k: ("%.2e" % v[0], v[1]) for k, v in worst.items()})
+        for name, (dev, it) in worst.items():
+            assert dev <= TRACK_BAND[dt][name], (dt, name, dev, it)
+        # no divergence: the deviation over the last five iterations is not an order of magnitude above the first five
+        for j, name in enumerate(("loss_gen_total", "loss_dis_total")):
+            early = max(abs(traj[dt][it][j] - traj["fp32"][it][j]) / max(1e-3, abs(traj["fp32"][it][j])) for it in range(5))
+            late = max(abs(traj[dt][it][j] - traj["fp32"][it][j]) / max(1e-3, abs(traj["fp32"][it][j])) for it in range(NIT - 5, NIT))
+            assert late <= max(10 * early, 0.5 * TRACK_BAND[dt][name]), (dt, name, early, late)
 
 
 def test_fp16_loss_scale_state_survives_a_checkpoint(T, tmp_path):
