@@ -28,7 +28,7 @@ int hip_fail(hipError_t e, const char* what) {
 static std::atomic<int> g_lanes{-1}, g_u_batch{-1}, g_norm_mask{-1};
 static std::atomic<long long> g_tuning_epoch{0};
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-int lanes_setting() { int v = g_lanes.load(); if (v < 0) { v = std::max(1, std::min(4, env_int("ACLGAN_LANES", 2))); g_lanes.store(v); } return v; }
+int lanes_setting() { int v = g_lanes.load(); if (v < 0) { v = std::max(1, std::min(4, env_int("ACLGAN_LANES", 3))); g_lanes.store(v); } return v; }
 int set_lanes(int v) { const int old = lanes_setting(); g_lanes.store(std::max(1, std::min(4, v))); return old; }
 int u_batch_setting() { int v = g_u_batch.load(); if (v < 0) { v = env_int("ACLGAN_U_BATCH", 1) ? 1 : 0; g_u_batch.store(v); } return v; }
 int set_u_batch(int v) { const int old = u_batch_setting(); g_u_batch.store(v ? 1 : 0); return old; }
@@ -94,10 +94,9 @@ int aclgan_winograd_filter_frag(const float* w, float* Uf, int Co, int Ci, int f
 int aclgan_conv3x3_winograd_fused(const float* x, const float* Uf, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int act, int reflect,
                                   int accumulate, float* stats, void* stream) {
     ACL_REQUIRE(x && Uf && y && B > 0, "conv3x3_winograd_fused: null argument");
-    const int old = wino_fused_mode();
-    set_wino_fused((old & ~15) | 2);      // (the entry point IS the fused kernel, whatever the step's switch and cost model say)
+    const int old = wino_fused_force(1);      // (the entry point IS the fused kernel, whatever the step's switch and cost model say: per thread)
     const int rc = wino_fused_launch(B, H, W, Cin, Cout, x, Uf, bias, y, act, accumulate, reflect, (float2*)stats, (hipStream_t)stream);
-    set_wino_fused(old);
+    wino_fused_force(old);
     if (rc == ACLGAN_EUNSUPPORTED) set_error("conv3x3_winograd_fused: shape not eligible (H, W multiples of 4, Cin of 16, Cout of 64, no tanh)");
     return rc;
 }

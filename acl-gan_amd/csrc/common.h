@@ -40,7 +40,7 @@ size_t colsum_ordered_bytes(int64_t M, int C);
 int colsum_ordered(const float* dy, float* db, int64_t M, int C, void* part, hipStream_t st);
 
 // Scheduler switches (aclgan_tuning / environment), read once per update:
-//   lanes (ACLGAN_LANES, default 2): HIP streams the independent branches of an update are spread over (engine.hip); 1 = one queue
+//   lanes (ACLGAN_LANES, default 3): HIP streams the independent branches of an update are spread over (engine.hip); 1 = one queue
 //   u_batch (ACLGAN_U_BATCH, default 1): batched Winograd filter transforms at the start of an update
 int lanes_setting();
 int set_lanes(int v);            // returns the previous value
@@ -173,6 +173,7 @@ int set_wino_x3(int v);
 // conv_wino_fused.hip (round 4): Winograd F(4x4,3x3) as ONE launch -- input transform, 36 frequency GEMMs, output transform
 int wino_fused_mode();                           // 0 off, 1 fused where the cost model says it pays, 2 fused wherever eligible
 int set_wino_fused(int v);                       // returns the previous mode
+int wino_fused_force(int on);                    // per-thread: > 0 = eligible shapes take the fused kernel whatever the mode; returns the previous value
 bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act = ACLGAN_ACT_NONE, int gph = 1, int kph = 1);
 int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st, int nph = 1);
 int wino_fused_launch(int B, int H, int W, int Cin_, int Cout_, const float* in, const float* Uf, const float* bias, float* out, int act, int accumulate,

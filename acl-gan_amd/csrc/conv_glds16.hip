@@ -381,10 +381,10 @@ __global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : (NBUF == 1 ? 4 :
 // 186.7 -- one 8-wave workgroup per CU has nothing to run while it waits at its barrier, two 4-wave workgroups cover each other.  So:
 // 128-row tiles by default; ACLGAN_GLDS_TILE = 2 / 3 forces 256 x 128 / 256 x 256 where the shape allows, 4 = the largest-tile rule
 // (kept tested: tests/test_gpu_ops16s.py runs every tile).  Returns 1 / 2 / 3.
-int g_tile_force = -1;
+std::atomic<int> g_tile_force{-1};      // (atomics: a switch set while another thread plans an update is seen old or new, never torn)
 int glds_tile(int rows, int N) {
-    int& force = g_tile_force;
-    if (force < 0) { const char* e = getenv("ACLGAN_GLDS_TILE"); force = e ? atoi(e) : 0; }
+    int force = g_tile_force.load();
+    if (force < 0) { const char* e = getenv("ACLGAN_GLDS_TILE"); force = e ? atoi(e) : 0; if (force < 0) force = 0; g_tile_force.store(force); }
     const int t256 = N % 256 == 0 ? cdiv(rows, 256) * (N / 256) : 0, t128 = N % 128 == 0 ? cdiv(rows, 256) * (N / 128) : 0;
     if (force == 3 && t256) return 3;
     if (force == 2 && t128) return 2;
@@ -863,19 +863,15 @@ bool enabled() {
 // which: 0 forward, 1 dgrad.  The forward also wants a grid that fills the chip without split-K (small late-discriminator maps keep the
 // split-K kernel of conv_fast16.hip, which reads the same 16-bit activations through its A16 path).
 // tuning / test knob behind aclgan_set_tuning("dgrad16s_direct", v); returns the previous value
-static int g_dgrad_direct = -1;
+static std::atomic<int> g_dgrad_direct{-1};
 int set_dgrad16s_direct(int v) {
-    if (g_dgrad_direct < 0) { const char* e = getenv("ACLGAN_DGRAD16S_DIRECT"); g_dgrad_direct = e ? (atoi(e) ? 1 : 0) : 0; }
-    const int old = g_dgrad_direct;
-    g_dgrad_direct = v ? 1 : 0;
-    return old;
+    if (g_dgrad_direct.load() < 0) { const char* e = getenv("ACLGAN_DGRAD16S_DIRECT"); g_dgrad_direct.store(e ? (atoi(e) ? 1 : 0) : 0); }
+    return g_dgrad_direct.exchange(v ? 1 : 0);
 }
 // tuning / test knob behind aclgan_set_tuning("glds_tile", v): same values as ACLGAN_GLDS_TILE; returns the previous value
 int set_glds_tile(int v) {
-    if (g_tile_force < 0) glds_tile(1, 1);
-    const int old = g_tile_force;
-    g_tile_force = v < 0 ? 0 : v;
-    return old;
+    if (g_tile_force.load() < 0) glds_tile(1, 1);
+    return g_tile_force.exchange(v < 0 ? 0 : v);
 }
 
 bool conv16s_ok(const ConvGeom& g, int which) {
@@ -927,8 +923,8 @@ int conv_dgrad16s(const ConvGeom& g, int dtype, const void* dy16, const void* w1
     // direct mode (ACLGAN_DGRAD16S_DIRECT=1): pixels without mirrored partners skip the scratch round trip, the fold touches the border band
     // only.  Bit-identical results (197 operator / step / determinism tests pass with it on) and no measurable gain: bf16 step 55.2 vs 55.2 ms,
     // fp16 B=32 184.1 vs 185.6 (same box, back to back) -- the fold was not on the critical path.  Off by default.
-    int& direct_on = g_dgrad_direct;
-    if (direct_on < 0) { const char* e = getenv("ACLGAN_DGRAD16S_DIRECT"); direct_on = e ? (atoi(e) ? 1 : 0) : 0; }
+    int direct_on = g_dgrad_direct.load();
+    if (direct_on < 0) { const char* e = getenv("ACLGAN_DGRAD16S_DIRECT"); direct_on = e ? (atoi(e) ? 1 : 0) : 0; g_dgrad_direct.store(direct_on); }
     p.dx = dx; p.Hi = g.Hi; p.Wi = g.Wi; p.pad = g.p; p.accumulate = accumulate;
     p.direct = (direct_on && dxst == dtype && g.Ci % 2 == 0) ? 1 : 0;
     int rc;

@@ -470,10 +470,11 @@ int wino_vec() {
 // bytes per value (+3.7 ms), the weight gradient loses the kept fp32 V (+1.6 ms) and, measured on the same box back to back, every
 // OTHER matrix kernel of the step runs 5-8 % slower while these launches are in the mix (the chip is power-limited: the bf16 pipes at
 // full rate cost the clocks of what follows): 121.3 against 119.9 ms of kernel time per step (profiles/r03_experiments.md).
-int g_wino_x3 = -1;
+std::atomic<int> g_wino_x3{-1};
 bool wino_x3() {
-    if (g_wino_x3 < 0) { const char* e = getenv("ACLGAN_WINO_X3"); g_wino_x3 = e ? (atoi(e) ? 1 : 0) : 0; }
-    return g_wino_x3 == 1;
+    int v = g_wino_x3.load();
+    if (v < 0) { const char* e = getenv("ACLGAN_WINO_X3"); v = e ? (atoi(e) ? 1 : 0) : 0; g_wino_x3.store(v); }
+    return v == 1;
 }
 // channels per thread of the input transform when it writes the three bf16 planes (ACLGAN_WINO_VEC3)
 int wino_vec3() {
@@ -555,7 +556,7 @@ bool conv_wino_ok(const ConvGeom& g) {
 // (U and V slots are sized for the three bf16 planes of the split-bf16 GEMM -- 6 bytes per value -- whether or not it runs; a layer's
 //  cached U is fp32 or planes for the whole update: the choice depends on the layer's shape and the process-wide switch only)
 // tuning / test knob behind aclgan_set_tuning("wino_x3", v); returns the previous value
-int set_wino_x3(int v) { const int old = wino_x3() ? 1 : 0; g_wino_x3 = v ? 1 : 0; return old; }
+int set_wino_x3(int v) { const int old = wino_x3() ? 1 : 0; g_wino_x3.store(v ? 1 : 0); return old; }
 size_t conv_wino_u_bytes(const ConvGeom& g) {
     if (conv_wino_ok(g)) return align256((size_t)36 * g.Co * g.Ci * 6);
     if (conv_up5_wino_ok(g)) return align256((size_t)144 * g.Co * g.Ci * 6);

@@ -459,7 +459,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
-int g_wino_fused = -1;
+std::atomic<int> g_wino_fused{-1};
+thread_local int tl_wino_force = 0;      // > 0: this thread's calls take the fused kernel wherever the shape is eligible (the operator entry point)
 
 }  // namespace
 
@@ -468,10 +469,15 @@ int g_wino_fused = -1;
 // returns the previous value.  ACLGAN_WINO_FUSED sets the default.  (bits 4.. select a measurement build when compiled with
 // -DACLGAN_FUSED_ABLATION)
 int wino_fused_mode() {
-    if (g_wino_fused < 0) { const char* e = getenv("ACLGAN_WINO_FUSED"); g_wino_fused = e ? atoi(e) : 1; if (g_wino_fused < 0 || (g_wino_fused & 15) > 2) g_wino_fused = 1; }
-    return g_wino_fused;
+    int v = g_wino_fused.load();
+    if (v < 0) { const char* e = getenv("ACLGAN_WINO_FUSED"); v = e ? atoi(e) : 1; if (v < 0 || (v & 15) > 2) v = 1; g_wino_fused.store(v); }
+    return v;
 }
-int set_wino_fused(int v) { const int old = wino_fused_mode(); g_wino_fused = (v < 0 || (v & 15) > 2) ? 1 : v; return old; }
+int set_wino_fused(int v) { const int old = wino_fused_mode(); g_wino_fused.store((v < 0 || (v & 15) > 2) ? 1 : v); return old; }
+// The operator entry point (aclgan_conv3x3_winograd_fused) IS the fused kernel whatever the step's switch says: a per-THREAD override
+// instead of flipping the process-wide switch around the launch (round 4 did; an update running on another thread saw the mode change
+// in the middle of its plan).  Returns the previous value.
+int wino_fused_force(int on) { const int old = tl_wino_force; tl_wino_force = on; return old; }
 
 // the fused kernel takes: K-side channels a multiple of 16, output channels a multiple of 64, byte offsets below 2^31; no tanh epilogue.
 // Mode 1 (default) additionally asks the cost model below whether the one-launch kernel PAYS for this grid; mode 2 takes it whenever the
@@ -482,7 +488,7 @@ int set_wino_fused(int v) { const int old = wino_fused_mode(); g_wino_fused = (v
 // scales with the tile count: 30 + 0.0488 us per (tile x 256 x 256 channel pair).  Crossover on the 256-channel ResBlock: ~1400 tiles (B = 5.5 at
 // 64 x 64); below it (the reference's own batch_size 3, the 64 x 64 B = 1 launch-floor probe) the pipeline is faster (B = 1: 42 against 93 us).
 bool wino_fused_ok(int B, int H, int W, int Cin_, int Cout_, int act, int gph, int kph) {
-    const int m = wino_fused_mode() & 15;
+    const int m = tl_wino_force > 0 ? 2 : (wino_fused_mode() & 15);
     if (m == 0) return false;
     const bool shape = act != ACLGAN_ACT_TANH && Cin_ % (2 * KC) == 0 && Cout_ % NBC == 0 && (long long)4 * 36 * Cin_ * Cout_ * 4 < 0x7fffffe0ll && H >= 4 && W >= 4 &&
                        (long long)B * (2 * H + 8) * (2 * W + 8) * std::max(Cin_, Cout_) * 4 < 0x7fffffe0ll;

@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) wgrad_fused_finish_kernel(const float* __
     }
 }
 
-int g_wgrad_fused = -1;
+std::atomic<int> g_wgrad_fused{-1};
 
 struct WgPlan { int TY, TXS, G, nblk, ks, gper; };
 WgPlan wg_plan(const ConvGeom& g) {
@@ -431,10 +431,11 @@ WgPlan wg_plan(const ConvGeom& g) {
 // tuning / test knob behind aclgan_set_tuning("wino_wgrad_fused", v): 0 = the pipeline of conv_wino.hip, 1 / 2 = the fused kernel wherever the
 // shape is eligible (it pays at every grid size measured); returns the previous value.  ACLGAN_WINO_WGRAD_FUSED sets the default.
 int wino_wgrad_fused_mode() {
-    if (g_wgrad_fused < 0) { const char* e = getenv("ACLGAN_WINO_WGRAD_FUSED"); g_wgrad_fused = e ? atoi(e) : 1; if (g_wgrad_fused < 0 || g_wgrad_fused > 2) g_wgrad_fused = 1; }
-    return g_wgrad_fused;
+    int v = g_wgrad_fused.load();
+    if (v < 0) { const char* e = getenv("ACLGAN_WINO_WGRAD_FUSED"); v = e ? atoi(e) : 1; if (v < 0 || v > 2) v = 1; g_wgrad_fused.store(v); }
+    return v;
 }
-int set_wino_wgrad_fused(int v) { const int old = wino_wgrad_fused_mode(); g_wgrad_fused = (v < 0 || v > 2) ? 1 : v; return old; }
+int set_wino_wgrad_fused(int v) { const int old = wino_wgrad_fused_mode(); g_wgrad_fused.store((v < 0 || v > 2) ? 1 : v); return old; }
 
 // 3x3 stride-1 reflect-pad-1 layers with W a multiple of 16, H of 4, Cout of 64, Cin of 32
 namespace {

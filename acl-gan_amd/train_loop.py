@@ -6,7 +6,7 @@ Works with any trainer that has the reference's surface (dis_update / gen_update
 the HIP trainer (acl-gan_amd/trainer.py) and the CPU oracle (tests only)."""
 
 
-def run_epochs(trainer, epoch, config, iterations=0, max_iter=None, z_source=None, on_iteration=None):
+def run_epochs(trainer, epoch, config, iterations=0, max_iter=None, z_source=None, on_iteration=None, epoch0=0):
     """Iterate like train.py:64-101.
 
     epoch()        -> iterable of (images_a, images_b): ONE pass over the zipped loaders (train.py:66); called again when exhausted
@@ -14,10 +14,15 @@ def run_epochs(trainer, epoch, config, iterations=0, max_iter=None, z_source=Non
     iterations     -> global iteration count to start from (trainer.resume's return value, train.py:64)
     z_source(kind) -> optional: the style noise of the next update (kind "dis" / "gen"), forwarded as z=...; None: the trainer draws it
     on_iteration(info) -> called after the updates of an iteration and BEFORE update_learning_rate (where the reference logs and
-                      snapshots, train.py:78-99) with {"iterations": global index, "it": per-epoch index, "ran_dis", "ran_gen"}
-    Returns the global iteration count when max_iter is reached (train.py:103-104 exits there)."""
+                      snapshots, train.py:78-99) with {"iterations": global index, "it": per-epoch index, "epoch": index of the pass
+                      (epoch0 + passes completed in this call), "ran_dis", "ran_gen"}
+    epoch0         -> index of the first pass (a resumed run continues its count: the loaders' per-epoch permutations are keyed by it)
+    Returns the global iteration count when max_iter is reached (train.py:103-104 exits there).
+    A pass that yields no batch at all (a dataset smaller than world x batch with drop_last) raises instead of spinning forever."""
     max_iter = config["max_iter"] if max_iter is None else max_iter
+    n_epoch = epoch0
     while True:
+        it = -1
         for it, (images_a, images_b) in enumerate(epoch()):
             ran_dis = it % config["D_update"] == 0            # train.py:71-72: on the per-epoch index
             ran_gen = it % config["G_update"] == 0            # train.py:73-74
@@ -32,11 +37,14 @@ def run_epochs(trainer, epoch, config, iterations=0, max_iter=None, z_source=Non
                 else:
                     trainer.gen_update(images_a, images_b, config, z=z_source("gen"))
             if on_iteration is not None:
-                on_iteration({"iterations": iterations, "it": it, "ran_dis": ran_dis, "ran_gen": ran_gen})
+                on_iteration({"iterations": iterations, "it": it, "epoch": n_epoch, "ran_dis": ran_dis, "ran_gen": ran_gen})
             trainer.update_learning_rate()                    # train.py:101: every iteration, whichever updates ran
             iterations += 1
             if iterations >= max_iter:                        # train.py:103-104
                 return iterations
+        if it < 0:
+            raise RuntimeError("run_epochs: a pass over the data yielded no batch (dataset smaller than world_size x batch_size?)")
+        n_epoch += 1
 
 
 def snapshot_due(iterations, config):

@@ -315,7 +315,7 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
  * Cin of 32).
  * key "lanes" (round 5): 1 .. 4 HIP streams the independent branches of an update are spread over (the two translation directions,
  * the reconstruction decodes, the discriminators and their scales: reference trainer.py:103-139, 258-286; csrc/engine.hip "Lanes");
- * 1 = one queue (the round-4 plan), default 2 (ACLGAN_LANES).  Results do not depend on it.  key "u_batch" (round 5): 1 (default) =
+ * 1 = one queue (the round-4 plan), default 3 (ACLGAN_LANES).  Results do not depend on it.  key "u_batch" (round 5): 1 (default) =
  * the Winograd transforms of all ResBlock filters of a network are one launch at the start of an update, 0 = one launch per filter at
  * its first use.  key "norm_mask" (round 5): 1 (default) = the backward of an activated normalisation layer recomputes the ReLU mask from x and
  * the forward's fused coefficients instead of reading y back (same mask: the same fmaf), 0 = reads y.  key "fault_at" (test hook; -1 = off): the backward replay of the next updates fails with ACLGAN_EHIP after that many

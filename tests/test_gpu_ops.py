@@ -196,6 +196,66 @@ def test_winograd_wgrad_fused_kernel(L, case):
         assert rel_err(out[2][0], out[0][0]) < 5e-5
 
 
+STRESS_FWD_CASES = [(3, 20, 28, 64, 64, 3, 1, 1, 0, "relu"),      # ragged tile rows / columns, reflect padding
+                    (2, 64, 64, 256, 256, 3, 1, 1, 0, "none"),    # the step's ResBlock shape (one workgroup per 8 x 4 tile block)
+                    (1, 16, 16, 128, 64, 5, 1, 2, 1, "none")]     # sub-pixel phases: four grid phases forward, four K phases in the input gradient
+
+
+@pytest.mark.parametrize("case", STRESS_FWD_CASES)
+def test_winograd_fused_kernels_repeat_launch_stress(L, case):
+    """Advisor (round 4): the two fused Winograd kernels carry hand-written MFMAs (`v_mfma` in VGPR form with "+v" operands) and, in the weight
+    gradient, inline-asm LDS reads with manual s_waitcnt -- hazards the compiler cannot see, held by the placement of sched_barriers.  The
+    round-4 race of exactly this kind (barriers publishing LDS-DMA copies) showed in 1 launch of 3 000.  So: thousands of back-to-back launches
+    of the forced fused forward, the fused input gradient (accumulate mode off) and the fused weight gradient, each compared BITWISE with the
+    first launch, with a busy second stream next to them (the side stream / lanes of the step change what shares a CU)."""
+    from gpu_util import conv_desc, nhwc, ohwi
+    import ctypes as C
+    B, Hi, Wi, Ci, Co, k, s, p, up, act = case
+    x, w, b = _case_tensors(case, 9)
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, act)
+    dn = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, "none")
+    xg, wg, bg = nhwc(x).cuda(), ohwi(w).cuda(), b.cuda()
+    Ho, Wo = (Hi << up), (Wi << up)
+    dyg = torch.randn(B, Ho, Wo, Co, generator=torch.Generator().manual_seed(4)).cuda()
+    fwd_scr = torch.empty(L.lib.aclgan_conv2d_fwd_scratch_bytes(C.byref(d)) // 4 + 16, device="cuda")
+    dg_scr = torch.empty(L.lib.aclgan_conv2d_dgrad_scratch_bytes(C.byref(dn)) // 4 + 16, device="cuda")
+    wg_scr = torch.empty(L.lib.aclgan_conv2d_wgrad_scratch_bytes(C.byref(dn)) // 4 + 16, device="cuda")
+    N = 1500
+    busy = torch.cuda.Stream()
+    noise = torch.randn(1 << 24, device="cuda")
+    old_f = L.lib.aclgan_set_tuning(b"wino_fused", 2); old_w = L.lib.aclgan_set_tuning(b"wino_wgrad_fused", 2)
+    try:
+        st = L.stream_ptr()
+        first = None
+        bad = {"fwd": 0, "dgrad": 0, "wgrad": 0}
+        for i in range(N):
+            if i % 50 == 0:
+                with torch.cuda.stream(busy):
+                    noise.mul_(1.0001)          # a streaming kernel on another queue
+            y = torch.empty(B, Ho, Wo, Co, device="cuda")
+            L.check(L.lib.aclgan_conv2d_fwd_ws(C.byref(d), L.ptr(xg), L.ptr(wg), L.ptr(bg), L.ptr(y), L.ptr(fwd_scr), st), "fwd")
+            dx = torch.empty(B, Hi, Wi, Ci, device="cuda")
+            L.check(L.lib.aclgan_conv2d_dgrad(C.byref(dn), L.ptr(dyg), L.ptr(wg), L.ptr(dx), L.ptr(dg_scr), 0, st), "dgrad")
+            cur = [y, dx]
+            if up == 0:
+                dw = torch.zeros(Co, k, k, Ci, device="cuda"); db = torch.zeros(Co, device="cuda")
+                L.check(L.lib.aclgan_conv2d_wgrad_ws(C.byref(dn), L.ptr(xg), L.ptr(dyg), L.ptr(dw), L.ptr(db), L.ptr(wg_scr), st), "wgrad")
+                cur += [dw, db]
+            if first is None:
+                first = cur
+                continue
+            bad["fwd"] += int(not torch.equal(cur[0], first[0]))
+            # (the border of dx also receives the reflection halo / the sub-pixel ring through fp32 atomics in the default mode: the fused kernel's
+            #  own output is the interior)
+            bad["dgrad"] += int(not torch.equal(cur[1][:, 3:-3, 3:-3], first[1][:, 3:-3, 3:-3]))
+            if up == 0:
+                bad["wgrad"] += int(not (torch.equal(cur[2], first[2]) and torch.equal(cur[3], first[3])))
+        torch.cuda.synchronize()
+        assert bad == {"fwd": 0, "dgrad": 0, "wgrad": 0}, (case, bad, N)
+    finally:
+        L.lib.aclgan_set_tuning(b"wino_fused", old_f); L.lib.aclgan_set_tuning(b"wino_wgrad_fused", old_w)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(L, case):
     from gpu_util import conv_desc, gpu_conv_dgrad, nhwc, nchw, ohwi, rel_err

@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--trainer", type=str, default="aclgan", help="aclgan")
     ap.add_argument("--synthetic", action="store_true", help="force synthetic U(-1,1) batches even if the dataset exists")
     ap.add_argument("--max_iter", type=int, default=None, help="override config max_iter")
+    ap.add_argument("--seed", type=int, default=None, help="seed of the run (noise, data order): default the config's `seed`, else 0; a resumed run takes the seed and "
+                    "the epoch count its checkpoint directory recorded (loop_state.json), so that the data order continues instead of restarting")
     opts = ap.parse_args()
     if opts.trainer != "aclgan":
         sys.exit("Only support aclgan")   # train.py:40-41
@@ -85,7 +87,19 @@ def main():
         dist.barrier()      # the checkpoint directory exists before any rank resumes from it
 
     iterations = trainer.resume(checkpoint_directory, hyperparameters=config) if opts.resume else 0
+    # The run's seed and the number of completed passes over the data live next to the checkpoints (loop_state.json, written with every
+    # snapshot): the per-epoch permutations of the sharded loaders are a function of (seed, epoch index), so a restart continues the
+    # sequence of the original run -- partial epochs of earlier restarts included -- instead of deriving an epoch from the iteration count
+    import json
+    state_path = os.path.join(checkpoint_directory, "loop_state.json")
+    loop_state = {}
+    if opts.resume and os.path.exists(state_path):
+        with open(state_path) as f:
+            loop_state = json.load(f)
+    seed = opts.seed if opts.seed is not None else int(loop_state.get("seed", config.get("seed", 0)))
+    torch.manual_seed(seed)      # (rank 0's torch seed is what aclgan_amd.data derives the shard seeds from; now it is the same after a restart)
     B, H, W = config["batch_size"], config["crop_image_height"], config["crop_image_width"]
+    epoch0 = int(loop_state.get("epoch", 0)) if opts.resume else 0
     gen = torch.Generator().manual_seed(1234 + rank)      # each rank its own shard of the synthetic global batch
     steps_per_epoch = 1000
 
@@ -108,8 +122,10 @@ def main():
         from aclgan_amd.data import get_all_data_loaders
         train_loader_a, train_loader_b, _, _ = get_all_data_loaders(config, device="cuda:%d" % local_rank, rank=rank, world_size=world)   # train.py:43
         if iterations and len(train_loader_a) and len(train_loader_b):           # resumed: do not replay the permutations of the epochs already seen
-            done = iterations // min(len(train_loader_a), len(train_loader_b))
+            # (recorded count; a checkpoint directory written before round 5 has none: every earlier epoch is then assumed complete)
+            done = int(loop_state.get("epoch", iterations // min(len(train_loader_a), len(train_loader_b))))
             train_loader_a.set_epoch(done); train_loader_b.set_epoch(done)
+            epoch0 = done
         epoch = lambda: zip(train_loader_a, train_loader_b)                      # train.py:66
         if is_main:
             print("data: %d / %d training images, device input pipeline, %d rank(s) x batch %d" % (len(train_loader_a.source), len(train_loader_b.source), world, B))
@@ -120,16 +136,28 @@ def main():
         iterations = info["iterations"]
         if is_main and log_due(iterations, config):
             vals = trainer._losses.cpu()          # one D2H copy, implies the sync of train.py:75
-            print("Iteration: %08d/%08d  %.3fs  " % (iterations + 1, max_iter, time.time() - clock["t0"]) +
+            # (wall time since the previous iteration ended: the updates AND the batch's decode / transform and the learning-rate step)
+            print("Iteration: %08d/%08d  %.3fs/it  " % (iterations + 1, max_iter, time.time() - clock["t0"]) +
                   " ".join("%s=%.4g" % (n[5:], float(vals[i])) for i, n in enumerate(L.LOSS_NAMES)
                            if n in ("loss_gen_total", "loss_dis_total", "loss_idt_A", "loss_gen_adv_A")))
         if is_main and snapshot_due(iterations, config):      # replicas are identical: rank 0's copy is THE checkpoint
             trainer.save(checkpoint_directory, iterations)
+            with open(state_path, "w") as f:
+                json.dump({"seed": seed, "epoch": info["epoch"], "iterations": iterations + 1}, f)
         clock["t0"] = time.time()
 
-    iterations = run_epochs(trainer, epoch, config, iterations=iterations, max_iter=max_iter, on_iteration=on_iteration)
+    last = {"epoch": epoch0}
+    _on = on_iteration
+
+    def on_iteration(info):      # noqa: F811  (remember the pass index for the final snapshot)
+        last["epoch"] = info["epoch"]
+        _on(info)
+
+    iterations = run_epochs(trainer, epoch, config, iterations=iterations, max_iter=max_iter, on_iteration=on_iteration, epoch0=epoch0)
     if is_main:
         trainer.save(checkpoint_directory, iterations - 1)
+        with open(state_path, "w") as f:
+            json.dump({"seed": seed, "epoch": last["epoch"], "iterations": iterations}, f)
         print("Finish training")
     if world > 1:
         dist.barrier()
