@@ -273,6 +273,7 @@ int aclgan_tuning(const char* key, int value, int* previous) {
     else if (!strcmp(key, "wino_fused")) old = set_wino_fused(value);
     else if (!strcmp(key, "wino_wgrad_fused")) old = set_wino_wgrad_fused(value);
     else if (!strcmp(key, "dgrad16s_direct")) old = set_dgrad16s_direct(value);
+    else if (!strcmp(key, "fwd16_patch")) old = set_fwd16_patch(value);
     else if (!strcmp(key, "lanes")) old = set_lanes(value);
     else if (!strcmp(key, "u_batch")) old = set_u_batch(value);
     else if (!strcmp(key, "norm_mask")) old = set_norm_mask(value);

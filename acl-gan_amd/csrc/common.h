@@ -168,6 +168,7 @@ bool conv16s_ok(const ConvGeom& g, int which);
 // stats (optional, conv_fwd16s_stats_chunk(g) > 0): [B][Ho*Wo / chunk][Co] (mean, M2) pairs of the STORED outputs -- norm_fwd's chunk partials
 int conv_fwd16s_stats_chunk(const ConvGeom& g);
 int set_glds_tile(int v);
+int set_fwd16_patch(int v);
 int set_dgrad16s_direct(int v);
 int set_wino_x3(int v);
 // conv_wino_fused.hip (round 4): Winograd F(4x4,3x3) as ONE launch -- input transform, 36 frequency GEMMs, output transform

@@ -376,6 +376,207 @@ __global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : (NBUF == 1 ? 4 :
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_fwd16p_kernel (round 5): the 3x3 stride-1 reflect-pad-1 convolutions (every ResBlock convolution, networks.py:297-310) with the
+// INPUT PATCH resident in LDS.
+//
+// What bounds conv_fwd16s on these layers is the ISSUE of its LDS-DMA copies, not their bytes and not the MFMAs: a
+// `buffer_load_dwordx4 ... lds` costs its wave 60 - 185 cycles at issue (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), the 128 x 128
+// tile needs 32 of them per k-tile = 8 per wave against 16 MFMAs of 32 cycles (profiles/r05_experiments.md section 3).  Per filter TAP
+// the A tile is the same set of input pixels shifted by one: nine taps re-copy a (rows + 2) x (W + 2) neighbourhood nine times.
+// Here a workgroup owns 256 consecutive output pixels = R = 256 / W full image rows; for each block of 64 input channels it copies the
+// (R + 2) x (W + 2) reflect-padded patch ONCE (W = 64: 396 pixel rows of 128 bytes instead of 9 x 256) and runs all nine taps from it --
+// the tap is a constant added to the patch row a lane's fragment read starts from.  8 waves (4 x 2, 64 x 64 each, the MFMA loop of
+// conv_fwd16s), 256 x 128 tile: per k-tile 16 weight pieces + ~5.5 patch pieces over 8 waves = 2.7 LDS-DMA issues per wave and 16 MFMAs
+// (conv_fwd16s: 8), the patch pieces spread one per tap.  LDS: 2 patch buffers of 400 rows + 2 weight buffers of 128 rows = 132 KB,
+// one workgroup per CU, two waves per SIMD.  Same swizzle (chunk ^ (row >> 1) & 7 on the DMA source side and in the fragment read), keyed
+// by the PATCH row: a lane group's 16 rows are consecutive pixels of one image row (W a multiple of 32), so the reads stay conflict-free.
+// Same epilogue as conv_fwd16s (bias, activation, 16-bit stores, normalisation partials per 256-row tile).
+constexpr int PATCH_ROWS = 400;      // >= (256 / W + 2) * (W + 2) for W = 64 (396) and W = 32 (340)
+template <class T, int WN, int TN>
+__global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = 2, WM = 4, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
+    static_assert(NW == 8, "eight waves");
+    constexpr int P_BYTES = PATCH_ROWS * ROWB, B_BYTES = BN * ROWB;
+    constexpr int P_IT = (PATCH_ROWS / 8 + NW - 1) / NW;      // patch pieces (8 rows = 1 KB) per wave: 7
+    constexpr int B_IT = BN / 8 / NW;                          // weight pieces per wave and k-tile: 2
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + 2 * B_BYTES + BM * 4];
+    unsigned char* const sB = smem + 2 * P_BYTES;
+    int* ro = reinterpret_cast<int*>(smem + 2 * P_BYTES + 2 * B_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = xcd_map(blockIdx.x, p.nwg);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int W = p.Wo, H = p.Ho, hw = H * W;
+    const int PW = W + 2, R = BM / W, P = (R + 2) * PW, npieces = (P + 7) >> 3;
+    const int bimg = m0 / hw, y0 = (m0 - bimg * hw) / W;      // the tile = rows y0 .. y0 + R - 1 of image bimg
+
+    for (int r = tid; r < BM; r += NT) ro[r] = m0 + r;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int cpt = p.Ci >> 6;                     // 64-channel blocks
+    const int nk = 9 * cpt;
+
+    // ---- LDS-DMA sources ----
+    const int lr = lane >> 3, lj = lane & 7;
+    int pvo[P_IT];                                 // patch piece n of this wave = piece n * 8 + wave: byte offset of this lane's row, chunk swizzled
+#pragma unroll
+    for (int n = 0; n < P_IT; ++n) {
+        const int piece = n * NW + wave;
+        int row = piece * 8 + lr;
+        if (row > P - 1) row = P - 1;             // (rows past the patch: a valid address, never read)
+        const int py = row / PW, px = row - py * PW;
+        const int iy = refl(y0 - 1 + py, H), ix = refl(px - 1, W);
+        const int prow = piece * 8 + lr;          // the LDS row it lands in decides the swizzle
+        pvo[n] = (((bimg * H + iy) * W + ix) * p.Ci + (lj ^ ((prow >> 1) & 7)) * 8) * 2;
+    }
+    int bvo[B_IT];
+#pragma unroll
+    for (int n = 0; n < B_IT; ++n) {
+        const int row = (BN / NW) * wave + 8 * n + lr;
+        bvo[n] = (min(n0 + row, p.Co - 1) * p.K + (lj ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x16, (long long)p.B * p.Hi * p.Wi * p.Ci * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w16, (long long)p.Co * p.K * 2);
+
+    auto issue_b = [&](int tap, int cc, int buf) __attribute__((always_inline)) {
+        unsigned char* db = sB + buf * B_BYTES + ((BN / NW) * wave) * ROWB;
+        const int koff = (tap * cpt + cc) * 128;  // the weights' k axis is (tap, cin)
+#pragma unroll
+        for (int n = 0; n < B_IT; ++n) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(db + n * 8 * ROWB), 16, bvo[n], koff, 0, 0);
+    };
+    auto issue_p = [&](int n, int cc, int buf) __attribute__((always_inline)) {      // patch piece n of this wave, channel block cc
+        const int piece = n * NW + wave;
+        if (piece < npieces)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + buf * P_BYTES + piece * 8 * ROWB), 16, pvo[n], cc * 128, 0, 0);
+    };
+
+    // ---- fragment read bases ----
+    const int l31 = lane & 31, kh = lane >> 5;
+    int pp0[TM];                                   // patch row of this lane's output pixel (tap (0, 0)), per 32-row block
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int r = wm * 64 + t * 32 + l31;
+        const int ry = r / W, rx_ = r - ry * W;
+        pp0[t] = ry * PW + rx_;
+    }
+    const int cb0 = kh ^ ((l31 >> 1) & 7);         // weight rows: swizzle by the tile row, as in mma_tile
+    const unsigned char* const bbase = sB + (wn * TN * 32 + l31) * ROWB;
+
+    // prologue: the whole first patch and the first weight tile
+#pragma unroll
+    for (int n = 0; n < P_IT; ++n) issue_p(n, 0, 0);
+    issue_b(0, 0, 0);
+    int kt = 0;
+    for (int cc = 0; cc < cpt; ++cc) {
+        const unsigned char* const pbuf = smem + (cc & 1) * P_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++kt) {
+            const int cur = kt & 1;
+            DMA_SYNCTHREADS();                     // every copy issued so far has landed, for every wave; the other buffers are free
+            if (kt + 1 < nk) { if (tap < 8) issue_b(tap + 1, cc, cur ^ 1); else issue_b(0, cc + 1, cur ^ 1); }
+            if (tap < P_IT && cc + 1 < cpt) issue_p(tap, cc + 1, (cc + 1) & 1);      // the next patch, one piece per tap
+            const int toff = (tap / 3) * PW + (tap % 3);
+            const unsigned char* const bb = bbase + cur * B_BYTES;
+            u32x4 fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int pp = pp0[t] + toff;
+                const int a0 = pp * ROWB + ((kh ^ ((pp >> 1) & 7)) << 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(pbuf + (a0 ^ (ks << 5)));
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(bb + t * 32 * ROWB + ((cb0 ^ (2 * ks)) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
+        }
+    }
+
+    const float* bias = p.bias;
+    const int act = p.act;
+    if (p.stats) {
+        // (mean, M2) of the BM = 256 STORED outputs of each channel of this tile = one chunk partial of norm_finalize_* (as in conv_fwd16s)
+        const int lh = lane >> 5;
+        float2* red = reinterpret_cast<float2*>(smem);
+        __syncthreads();                           // every wave is done with the operand buffers
+        auto col = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int n = n0 + wn * TN * 32 + j * 32 + l31;
+            const float bv = (bias && n < p.Co) ? bias[n] : 0.f;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = act_apply(acc[i][j][r] + bv, act);
+                    if (p.yst != ST_F32) v = st_unpack2(st_pack2(v, 0.f, p.yst), p.yst)[0];     // the value as it will be stored
+                    acc[i][j][r] = v;
+                    sum += v;
+                }
+            float mean = sum * (1.f / 32.f), q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float dv = acc[i][j][r] - mean; q += dv * dv; }
+            const float om = __shfl_xor(mean, 32), oq = __shfl_xor(q, 32);
+            const float dm = om - mean;
+            q = q + oq + dm * dm * 16.f;
+            mean = 0.5f * (mean + om);
+            if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + l31] = make_float2(mean, q);
+        };
+        col(std::integral_constant<int, 0>{});
+        if constexpr (TN > 1) col(std::integral_constant<int, 1>{});
+        if constexpr (TN > 2) { col(std::integral_constant<int, 2>{}); col(std::integral_constant<int, 3>{}); }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Co) {
+            float cnt = 64.f, mean = red[tid].x, m2 = red[tid].y;
+#pragma unroll
+            for (int i = 1; i < WM; ++i) {
+                const float2 o = red[i * BN + tid];
+                const float dm = o.x - mean, tot = cnt + 64.f;
+                mean += dm * (64.f / tot);
+                m2 += o.y + dm * dm * (cnt * 64.f / tot);
+                cnt = tot;
+            }
+            p.stats[(size_t)(m0 / BM) * p.Co + n0 + tid] = make_float2(mean, m2);
+        }
+        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Co, p.Co, p.y, p.yst, lane, [](float v, int) { return v; });
+    } else {
+        __syncthreads();                           // (ro was written before the main loop's first barrier; keep the waves together for the stores)
+        store_acc<TM, TN>(acc, ro, wm * 64, n0 + wn * TN * 32, p.Co, p.Co, p.y, p.yst, lane,
+                          [&](float v, int n) { return act_apply(v + (bias ? bias[n] : 0.f), act); });
+    }
+#endif
+}
+// shapes the patch kernel takes, and whether it is on (aclgan_tuning "fwd16_patch" / ACLGAN_FWD16_PATCH; default: see launch_fwd16s)
+std::atomic<int> g_fwd16_patch{-1};
+int fwd16_patch_mode() {
+    int v = g_fwd16_patch.load();
+    if (v < 0) { const char* e = getenv("ACLGAN_FWD16_PATCH"); v = e ? (atoi(e) ? 1 : 0) : 1; g_fwd16_patch.store(v); }
+    return v;
+}
+bool fwd16p_shape_ok(const ConvGeom& g) {
+    if (!(g.k == 3 && g.s == 1 && g.p == 1 && g.up == 0 && g.Hi == g.Ho && g.Wi == g.Wo)) return false;
+    if (!(g.Wo == 32 || g.Wo == 64) || (g.Ho * g.Wo) % 256 != 0 || g.Ho < 2) return false;
+    if (g.Ci % 64 != 0 || g.Co % 128 != 0) return false;
+    if ((256 / g.Wo + 2) * (g.Wo + 2) > PATCH_ROWS) return false;
+    return (g.M / 256) * (g.Co / 128) >= 64;       // (one workgroup per CU: a quarter of the chip at least; smaller grids keep the 4-wave tiles)
+}
+
 // tile choice.  Measured inside the step (profiles/r03_experiments.md, same box back to back) the 8-wave tiles LOSE although they move fewer
 // operand bytes per MFMA: bf16 B=8 56.3 ms with 128-row tiles against 60.4 with "largest tile that fills the chip", fp16 B=32 182.4 against
 // 186.7 -- one 8-wave workgroup per CU has nothing to run while it waits at its barrier, two 4-wave workgroups cover each other.  So:
@@ -403,6 +604,12 @@ bool glds_spec() {
 
 template <class T>
 int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
+    if (fwd16_patch_mode() && fwd16p_shape_ok(g)) {      // 3x3 ResBlock shapes: the input patch stays in LDS for all nine taps
+        p.tiles_n = g.Co / 128; p.nwg = (g.M / 256) * p.tiles_n;
+        hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2>), dim3(p.nwg), dim3(512), 0, st, p);
+        ACL_CHECK_LAUNCH("conv_fwd16p_kernel");
+        return ACLGAN_OK;
+    }
     const int tc = glds_tile(g.M, g.Co);
     static int force = -1;
     if (force < 0) { const char* e = getenv("ACLGAN_GLDS_NBUF"); force = e ? atoi(e) : 0; }
@@ -868,6 +1075,8 @@ int set_dgrad16s_direct(int v) {
     if (g_dgrad_direct.load() < 0) { const char* e = getenv("ACLGAN_DGRAD16S_DIRECT"); g_dgrad_direct.store(e ? (atoi(e) ? 1 : 0) : 0); }
     return g_dgrad_direct.exchange(v ? 1 : 0);
 }
+// tuning knob "fwd16_patch": 1 = the 3x3 stride-1 layers it fits run on conv_fwd16p_kernel (input patch resident in LDS), 0 = on conv_fwd16s
+int set_fwd16_patch(int v) { const int old = fwd16_patch_mode(); g_fwd16_patch.store(v ? 1 : 0); return old; }
 // tuning / test knob behind aclgan_set_tuning("glds_tile", v): same values as ACLGAN_GLDS_TILE; returns the previous value
 int set_glds_tile(int v) {
     if (g_tile_force.load() < 0) glds_tile(1, 1);
@@ -888,7 +1097,7 @@ int conv_fwd16s_stats_chunk(const ConvGeom& g) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("ACLGAN_NOSTATFUSE"); off = (e && atoi(e)) ? 1 : 0; }
     if (off || !conv16s_ok(g, 0)) return 0;
-    const int rows = glds_tile(g.M, g.Co) >= 2 ? 256 : 128;      // the statistics chunk is the launch's row tile
+    const int rows = (fwd16_patch_mode() && fwd16p_shape_ok(g)) ? 256 : (glds_tile(g.M, g.Co) >= 2 ? 256 : 128);      // the statistics chunk is the launch's row tile
     return (g.Ho * g.Wo) % rows == 0 ? rows : 0;
 }
 

@@ -324,6 +324,7 @@ struct aclgan_ctx {
     std::vector<hipEvent_t> lane_evs[MAXL];          // lane_evs[l][k]: the k-th checkpoint of lane l in this step
     int seen[MAXL][MAXL] = {};                       // seen[d][s]: lane d has waited for the first seen[d][s] checkpoints of lane s
     size_t hw[MAXL] = {0, 0, 0, 0};
+    bool lane_dirty[MAXL] = {false, false, false, false};   // something (work or a wait) was enqueued on the lane since its last checkpoint
     int pass_seq = 0, cur_pass_id = -1;              // forward pass ids (always on; the roctx labels are separate)
     hipStream_t lane_stream(int l) const { return l == 0 ? st0 : lane_st[l]; }
     int nck(int l) const { return (int)lane_evs[l].size(); }
@@ -332,7 +333,7 @@ struct aclgan_ctx {
         nlanes = std::max(1, std::min(want, (int)MAXL));
         if (!side_enabled()) nlanes = 1;             // parameter gradients need their own ordered stream once there is more than one lane
         cur_lane = 0; st0 = st;
-        for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
+        for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; lane_dirty[l] = false; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
         ev_next = 0;
         if (dry) return ACLGAN_OK;
         // (parameter-gradient stream first, then the lanes: with the caller's stream that is one hardware queue each up to 3 lanes)
@@ -356,6 +357,7 @@ struct aclgan_ctx {
             if (rc != hipSuccess) return aclgan::hip_fail(rc, "lane checkpoint");
         }
         lane_evs[l].push_back(ev);
+        lane_dirty[l] = false;
         return ACLGAN_OK;
     }
     // pass boundary on the current lane (stamps taken before it are covered by this checkpoint)
@@ -367,6 +369,7 @@ struct aclgan_ctx {
         int rc = checkpoint(cur_lane);
         if (rc) return rc;
         cur_lane = l;
+        lane_dirty[l] = true;
         if (!dry) st = lane_stream(l);
         return ACLGAN_OK;
     }
@@ -382,6 +385,7 @@ struct aclgan_ctx {
             hipError_t e = hipStreamWaitEvent(lane_stream(d), lane_evs[s][k], 0);
             if (e != hipSuccess) return aclgan::hip_fail(e, "lane wait");
         }
+        lane_dirty[d] = true;
         seen[d][s] = k + 1;
         return ACLGAN_OK;
     }
@@ -414,8 +418,12 @@ struct aclgan_ctx {
         if (nlanes > 1) {
             int rc = set_lane(0);
             if (rc) return rc;
-            for (int l = 1; l < nlanes; ++l)
+            // (a lane that only ever received a wait -- the barrier's -- still has to come back: under stream capture every stream that
+            //  joined the capture must be joined again before it ends)
+            for (int l = 1; l < nlanes; ++l) {
+                if (lane_dirty[l]) { rc = checkpoint(l); if (rc) return rc; }
                 if (nck(l) > 0) { rc = wait_ck(0, l, nck(l) - 1); if (rc) return rc; }
+            }
         }
         return side_join();
     }
@@ -453,7 +461,7 @@ struct aclgan_ctx {
         top2 = 0;
         keep_total = 0;
         ucache.clear();
-        for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
+        for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; lane_dirty[l] = false; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
         ev_next = 0; cur_lane = 0; nlanes = 1; pass_seq = 0; cur_pass_id = -1;
         if (st0) { st = st0; st0 = nullptr; }
     }

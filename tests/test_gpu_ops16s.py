@@ -55,6 +55,7 @@ CASES = [
     (7, 62, 66, 256, 64, 3, 1, 1, "none"),      # dgrad: N = Cin = 256 -> 256 x 128 tiles over the padded grid, ragged last tile
     (15, 62, 62, 256, 64, 3, 1, 1, "none"),     # dgrad: 256 x 256 tiles
     (8, 64, 64, 128, 256, 4, 2, 1, "none"),     # stride 2 with big tiles on the dgrad side (four parity classes of the padded grid)
+    (16, 32, 32, 128, 256, 3, 1, 1, "relu"),    # round 5: the patch-resident forward kernel on a 32-wide map (8 image rows per tile, two channel blocks)
 ]
 
 
@@ -77,6 +78,13 @@ def _packs(L, w_ohwi, dt):
 
 def _r(t, dt):
     return t.to(TDT[dt]).float()
+
+
+def _patch_on(L):
+    prev = C.c_int()
+    L.check(L.lib.aclgan_tuning(b"fwd16_patch", 1, C.byref(prev)), "tuning")
+    L.check(L.lib.aclgan_tuning(b"fwd16_patch", prev.value, None), "tuning")
+    return prev.value != 0
 
 
 def _rel(a, b):
@@ -127,6 +135,51 @@ def test_conv_fwd16s(L, case, dt, tile):
     assert torch.equal(y32, y2)
 
 
+PATCH_CASES = [CASES[0], CASES[6], CASES[7], CASES[11], (4, 64, 64, 128, 128, 3, 1, 1, "lrelu")]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv_fwd16p_patch_kernel(L, case, dt):
+    """conv_fwd16p_kernel (round 5, csrc/conv_glds16.hip): the 3x3 stride-1 reflect-pad-1 layers with the input patch of a 256-pixel tile
+    resident in LDS for all nine taps.  Taken by default where the shape fits (these cases: 64- and 32-wide maps, one / two / four channel
+    blocks, both image borders inside one tile); against the exact oracle on the rounded operands like every 16-bit kernel, against
+    conv_fwd16s (tuning fwd16_patch = 0: same products, another summation order), 16-bit output == fp32 output rounded once, run to run bits,
+    and the launch really is the patch kernel (one launch either way, so the check is on the statistics chunk it reports: 256 rows)."""
+    from gpu_util import conv_desc, nhwc, nchw, ohwi
+    B, Hi, Wi, Ci, Co, k, s, p, act = case
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, 0, act)
+    x, w, b = _t(case, 0)
+    wg, bg = ohwi(w).cuda(), b.cuda()
+    x16 = nhwc(x).cuda().to(TDT[dt])
+    w16, _ = _packs(L, wg, dt)
+    exact = O.conv_block(_r(x, dt).double(), _r(w, dt).double(), b.double(), s, p, act)
+    code = L.DTYPE[dt]
+    out = {}
+    prev = C.c_int()
+    L.check(L.lib.aclgan_tuning(b"fwd16_patch", 1, C.byref(prev)), "tuning")
+    try:
+        for mode in (1, 0):
+            L.check(L.lib.aclgan_tuning(b"fwd16_patch", mode, None), "tuning")
+            chunk = L.lib.aclgan_conv2d_fwd16s_stats_chunk(C.byref(d))
+            y32 = torch.full((B, Hi, Wi, Co), float("nan"), device="cuda")
+            L.check(L.lib.aclgan_conv2d_fwd16s(C.byref(d), code, L.ptr(x16), L.ptr(w16), L.ptr(bg), L.ptr(y32), 0, L.stream_ptr()), "conv2d_fwd16s")
+            y16 = torch.full((B, Hi, Wi, Co), float("nan"), device="cuda").to(TDT[dt])
+            L.check(L.lib.aclgan_conv2d_fwd16s(C.byref(d), code, L.ptr(x16), L.ptr(w16), L.ptr(bg), L.ptr(y16), code, L.stream_ptr()), "conv2d_fwd16s")
+            y2 = torch.empty_like(y32)
+            L.check(L.lib.aclgan_conv2d_fwd16s(C.byref(d), code, L.ptr(x16), L.ptr(w16), L.ptr(bg), L.ptr(y2), 0, L.stream_ptr()))
+            out[mode] = (y32, y16, y2, chunk)
+    finally:
+        L.check(L.lib.aclgan_tuning(b"fwd16_patch", prev.value, None), "tuning")
+    assert out[1][3] == 256, "the patch kernel was not taken for %r (statistics chunk %d)" % (case, out[1][3])
+    for mode in (1, 0):
+        y32, y16, y2, _ = out[mode]
+        assert _rel(nchw(y32), exact) < EXACT_TOL, (mode, _rel(nchw(y32), exact))
+        assert torch.equal(y16, y32.to(TDT[dt]))
+        assert torch.equal(y32, y2)
+    assert _rel(out[1][0], out[0][0]) < 1e-5
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("yst", [0, 1])
 @pytest.mark.parametrize("case", [CASES[0], (4, 32, 32, 64, 64, 3, 1, 1, "none"), CASES[6], CASES[7], (16, 32, 32, 64, 128, 3, 1, 1, "relu")])
@@ -138,7 +191,7 @@ def test_conv_fwd16s_epilogue_statistics(L, case, dt, yst, tile):
     d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, 0, act)
     R = L.lib.aclgan_conv2d_fwd16s_stats_chunk(C.byref(d))
     assert R in (128, 256), "every case here is a shape the step fuses the statistics for"
-    if case in (CASES[6], CASES[7]): assert R == (256 if tile == 4 else 128)
+    if case in (CASES[6], CASES[7]): assert R == (256 if (tile == 4 or _patch_on(L)) else 128)      # (3x3 on a 64-wide map: the patch kernel's 256-row tiles when it is on)
     x, w, b = _t(case, 2)
     wg, bg = ohwi(w).cuda(), b.cuda()
     x16 = nhwc(x).cuda().to(TDT[dt])
