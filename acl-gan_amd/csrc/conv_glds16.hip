@@ -392,18 +392,28 @@ __global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : (NBUF == 1 ? 4 :
 // one workgroup per CU, two waves per SIMD.  Same swizzle (chunk ^ (row >> 1) & 7 on the DMA source side and in the fragment read), keyed
 // by the PATCH row: a lane group's 16 rows are consecutive pixels of one image row (W a multiple of 32), so the reads stay conflict-free.
 // Same epilogue as conv_fwd16s (bias, activation, 16-bit stores, normalisation partials per 256-row tile).
+//
+// PP = 1 (the default form): the two waves of every SIMD work in COUNTER-PHASE (MI355X_MICROARCH.md "Two waves per SIMD"): the interval between
+// two s_barriers is a LOAD segment for one half of the workgroup (waves 0-3: 16 ds_read_b128 of its next fragments, then its share of
+// the LDS-DMA issues for the tile after next) and a COMPUTE segment (16 MFMAs on fragments already in registers) for the other half
+// (waves 4-7, one per SIMD), and the roles swap at every barrier -- in the PP = 0 form all eight waves copy, read and multiply in lockstep,
+// so a SIMD's matrix pipe idles through both of its waves' copy + read phases (measured: 48 us, 0.32 of the MFMA roof; PP = 1: see
+// profiles/r05_experiments.md section 3).  Three weight buffers (a tile is overwritten two intervals after its last reader), copies are
+// waited for at the end of the issuing wave's next COMPUTE segment: a full segment of latency cover, no wait in front of a read.
 constexpr int PATCH_ROWS = 400;      // >= (256 / W + 2) * (W + 2) for W = 64 (396) and W = 32 (340)
-template <class T, int WN, int TN>
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); WG_BARRIER(); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <class T, int WN, int TN, int PP>
 __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = 2, WM = 4, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
     static_assert(NW == 8, "eight waves");
+    constexpr int NB = PP ? 3 : 2;                             // weight buffers
     constexpr int P_BYTES = PATCH_ROWS * ROWB, B_BYTES = BN * ROWB;
     constexpr int P_IT = (PATCH_ROWS / 8 + NW - 1) / NW;      // patch pieces (8 rows = 1 KB) per wave: 7
     constexpr int B_IT = BN / 8 / NW;                          // weight pieces per wave and k-tile: 2
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + 2 * B_BYTES + BM * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + NB * B_BYTES + BM * 4];
     unsigned char* const sB = smem + 2 * P_BYTES;
-    int* ro = reinterpret_cast<int*>(smem + 2 * P_BYTES + 2 * B_BYTES);
+    int* ro = reinterpret_cast<int*>(smem + 2 * P_BYTES + NB * B_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -470,6 +480,7 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
     const int cb0 = kh ^ ((l31 >> 1) & 7);         // weight rows: swizzle by the tile row, as in mma_tile
     const unsigned char* const bbase = sB + (wn * TN * 32 + l31) * ROWB;
 
+    if constexpr (PP == 0) {
     // prologue: the whole first patch and the first weight tile
 #pragma unroll
     for (int n = 0; n < P_IT; ++n) issue_p(n, 0, 0);
@@ -504,6 +515,72 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
         }
+    }
+    } else {
+    // ---- counter-phase schedule ----
+    // intervals I0, I1, ... between consecutive barriers:   half 0: LOAD(0) COMPUTE(0) LOAD(1) COMPUTE(1) ...
+    //                                                        half 1:  idle   LOAD(0) COMPUTE(0) LOAD(1)   ...
+    // tile t is read in I(2t) (half 0) and I(2t+1) (half 1); its copies are issued in LOAD(t-2) of either half (I(2t-4), I(2t-3)), waited
+    // for at the end of that wave's COMPUTE(t-2) (I(2t-3), I(2t-2)) and so published by the barrier in front of I(2t-1); they overwrite
+    // tile t-3, last read in I(2t-5).  The next patch (one piece per wave and tap) lands in the other patch buffer the same way.
+    const int half = wave >> 2;
+#pragma unroll
+    for (int n = 0; n < P_IT; ++n) issue_p(n, 0, 0);
+    issue_b(0, 0, 0);
+    if (nk > 1) issue_b(1 % 9, 1 / 9, 1);          // (tile 1: tap 1 of channel block 0 -- nk = 9 cpt >= 9)
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    PP_BARRIER();                                   // patch 0 and tiles 0, 1 are in LDS for every wave; the row table too
+    if (half == 1) PP_BARRIER();                    // half 1 sits out I0
+    int tap = 0, cc = 0;                            // tile kt = (cc, tap)
+    int tap2 = 2, cc2 = 0;                          // tile kt + 2
+    int brd = 0, bwr = 2;                           // weight buffer of tile kt / of tile kt + 2
+    int ty = 0, tx = 0;                             // tap = 3 ty + tx
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- LOAD(kt): fragments first, copies last (nothing in front of the reads that could wait for a copy issued here) ----
+        const unsigned char* const pbuf = smem + (cc & 1) * P_BYTES;
+        const unsigned char* const bb = bbase + brd * B_BYTES;
+        const int toff = ty * PW + tx;
+        u32x4 fa[TM][4], fb[TN][4];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int pp = pp0[t] + toff;
+            const int a0 = pp * ROWB + ((kh ^ ((pp >> 1) & 7)) << 4);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(pbuf + (a0 ^ (ks << 5)));
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(bb + t * 32 * ROWB + ((cb0 ^ (2 * ks)) << 4));
+        if (kt + 2 < nk) issue_b(tap2, cc2, bwr);
+        if (tap < P_IT && cc + 1 < cpt) {           // the next patch, one piece per wave and tap
+            const int piece = tap * NW + wave;
+            if (piece < npieces) {
+                int off = pvo[0];
+#pragma unroll
+                for (int n = 1; n < P_IT; ++n) off = tap == n ? pvo[n] : off;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((cc + 1) & 1) * P_BYTES + piece * 8 * ROWB), 16, off, (cc + 1) * 128, 0, 0);
+            }
+        }
+        PP_BARRIER();
+        // ---- COMPUTE(kt) ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);          // (the wait stays BEHIND the MFMAs: hoisted to the head of the segment it would stall them)
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));   // the copies of LOAD(kt) have had this whole segment to land
+        PP_BARRIER();
+        // next tile
+        if (++tx == 3) { tx = 0; ++ty; }
+        if (++tap == 9) { tap = 0; ty = 0; tx = 0; ++cc; }
+        if (++tap2 == 9) { tap2 = 0; ++cc2; }
+        brd = brd == NB - 1 ? 0 : brd + 1;
+        bwr = bwr == NB - 1 ? 0 : bwr + 1;
+    }
+    if (half == 0) PP_BARRIER();                    // (every wave passes the same number of barriers)
     }
 
     const float* bias = p.bias;
@@ -566,7 +643,7 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
 std::atomic<int> g_fwd16_patch{-1};
 int fwd16_patch_mode() {
     int v = g_fwd16_patch.load();
-    if (v < 0) { const char* e = getenv("ACLGAN_FWD16_PATCH"); v = e ? (atoi(e) ? 1 : 0) : 1; g_fwd16_patch.store(v); }
+    if (v < 0) { const char* e = getenv("ACLGAN_FWD16_PATCH"); v = e ? atoi(e) : 1; if (v < 0 || v > 2) v = 1; g_fwd16_patch.store(v); }
     return v;
 }
 bool fwd16p_shape_ok(const ConvGeom& g) {
@@ -606,7 +683,8 @@ template <class T>
 int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
     if (fwd16_patch_mode() && fwd16p_shape_ok(g)) {      // 3x3 ResBlock shapes: the input patch stays in LDS for all nine taps
         p.tiles_n = g.Co / 128; p.nwg = (g.M / 256) * p.tiles_n;
-        hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2>), dim3(p.nwg), dim3(512), 0, st, p);
+        if (fwd16_patch_mode() == 2) hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 0>), dim3(p.nwg), dim3(512), 0, st, p);      // lockstep form (measurement)
+        else hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1>), dim3(p.nwg), dim3(512), 0, st, p);
         ACL_CHECK_LAUNCH("conv_fwd16p_kernel");
         return ACLGAN_OK;
     }
@@ -1076,7 +1154,7 @@ int set_dgrad16s_direct(int v) {
     return g_dgrad_direct.exchange(v ? 1 : 0);
 }
 // tuning knob "fwd16_patch": 1 = the 3x3 stride-1 layers it fits run on conv_fwd16p_kernel (input patch resident in LDS), 0 = on conv_fwd16s
-int set_fwd16_patch(int v) { const int old = fwd16_patch_mode(); g_fwd16_patch.store(v ? 1 : 0); return old; }
+int set_fwd16_patch(int v) { const int old = fwd16_patch_mode(); g_fwd16_patch.store((v < 0 || v > 2) ? 1 : v); return old; }
 // tuning / test knob behind aclgan_set_tuning("glds_tile", v): same values as ACLGAN_GLDS_TILE; returns the previous value
 int set_glds_tile(int v) {
     if (g_tile_force.load() < 0) glds_tile(1, 1);

@@ -159,7 +159,7 @@ def test_conv_fwd16p_patch_kernel(L, case, dt):
     prev = C.c_int()
     L.check(L.lib.aclgan_tuning(b"fwd16_patch", 1, C.byref(prev)), "tuning")
     try:
-        for mode in (1, 0):
+        for mode in (1, 2, 0):      # 1: the two waves of a SIMD in counter-phase (default), 2: all waves in lockstep, 0: conv_fwd16s
             L.check(L.lib.aclgan_tuning(b"fwd16_patch", mode, None), "tuning")
             chunk = L.lib.aclgan_conv2d_fwd16s_stats_chunk(C.byref(d))
             y32 = torch.full((B, Hi, Wi, Co), float("nan"), device="cuda")
@@ -171,12 +171,13 @@ def test_conv_fwd16p_patch_kernel(L, case, dt):
             out[mode] = (y32, y16, y2, chunk)
     finally:
         L.check(L.lib.aclgan_tuning(b"fwd16_patch", prev.value, None), "tuning")
-    assert out[1][3] == 256, "the patch kernel was not taken for %r (statistics chunk %d)" % (case, out[1][3])
-    for mode in (1, 0):
+    assert out[1][3] == 256 and out[2][3] == 256, "the patch kernel was not taken for %r (statistics chunk %d)" % (case, out[1][3])
+    for mode in (1, 2, 0):
         y32, y16, y2, _ = out[mode]
         assert _rel(nchw(y32), exact) < EXACT_TOL, (mode, _rel(nchw(y32), exact))
         assert torch.equal(y16, y32.to(TDT[dt]))
         assert torch.equal(y32, y2)
+    assert torch.equal(out[1][0], out[2][0])      # the two schedules of the patch kernel add the same products in the same order
     assert _rel(out[1][0], out[0][0]) < 1e-5
 
 
