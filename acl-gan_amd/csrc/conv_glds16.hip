@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = 2, WM = 4, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
     static_assert(NW == 8, "eight waves");
-    constexpr int NB = PP ? 3 : 2;                             // weight buffers
+    constexpr int NB = 3;                                      // weight buffers: a tile is overwritten two k-tiles after its last reader
     constexpr int P_BYTES = PATCH_ROWS * ROWB, B_BYTES = BN * ROWB;
     constexpr int P_IT = (PATCH_ROWS / 8 + NW - 1) / NW;      // patch pieces (8 rows = 1 KB) per wave: 7
     constexpr int B_IT = BN / 8 / NW;                          // weight pieces per wave and k-tile: 2
@@ -481,40 +481,64 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
     const unsigned char* const bbase = sB + (wn * TN * 32 + l31) * ROWB;
 
     if constexpr (PP == 0) {
-    // prologue: the whole first patch and the first weight tile
+    // ---- lockstep schedule, weight tiles TWO k-tiles ahead ----
+    // k-tile kt: wait until everything but the copies issued in k-tile kt-1 (tile kt+1, a patch piece) has landed -> tile kt is in LDS;
+    // barrier (every wave has it, every wave is done reading tile kt-1); issue tile kt+2 into the buffer of tile kt-1; multiply tile kt.
+    // A copy has two full k-tiles to land (one in the two-buffer form: under the load of 256 workgroups copying in bursts behind the same
+    // barrier an LDS-DMA copy takes ~1 us issue -> landed, longer than a k-tile's MFMAs -- profiles/r05_experiments.md section 3).
 #pragma unroll
     for (int n = 0; n < P_IT; ++n) issue_p(n, 0, 0);
     issue_b(0, 0, 0);
-    int kt = 0;
-    for (int cc = 0; cc < cpt; ++cc) {
-        const unsigned char* const pbuf = smem + (cc & 1) * P_BYTES;
+    issue_b(1, 0, 1);
+    int tap = 0, cc = 0, tap2 = 2, cc2 = 0, brd = 0, bwr = 2, ty = 0, tx = 0;
+    int issued_prev = B_IT;                          // copies of the newest tile in flight (tile 1): the wait leaves exactly those outstanding
+    for (int kt = 0; kt < nk; ++kt) {
+        if (issued_prev >= B_IT + 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(B_IT + 1));
+        else if (issued_prev == B_IT) __builtin_amdgcn_s_waitcnt(vmcnt_imm(B_IT));
+        else if (issued_prev == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(1));
+        else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        __builtin_amdgcn_sched_barrier(0);
+        WG_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        int issued = 0;
+        if (kt + 2 < nk) { issue_b(tap2, cc2, bwr); issued += B_IT; }
+        if (tap < P_IT && cc + 1 < cpt) {           // the next patch, one piece per wave and tap
+            const int piece = tap * NW + wave;
+            if (piece < npieces) {
+                int off = pvo[0];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++kt) {
-            const int cur = kt & 1;
-            DMA_SYNCTHREADS();                     // every copy issued so far has landed, for every wave; the other buffers are free
-            if (kt + 1 < nk) { if (tap < 8) issue_b(tap + 1, cc, cur ^ 1); else issue_b(0, cc + 1, cur ^ 1); }
-            if (tap < P_IT && cc + 1 < cpt) issue_p(tap, cc + 1, (cc + 1) & 1);      // the next patch, one piece per tap
-            const int toff = (tap / 3) * PW + (tap % 3);
-            const unsigned char* const bb = bbase + cur * B_BYTES;
-            u32x4 fa[TM][4], fb[TN][4];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const int pp = pp0[t] + toff;
-                const int a0 = pp * ROWB + ((kh ^ ((pp >> 1) & 7)) << 4);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(pbuf + (a0 ^ (ks << 5)));
+                for (int n = 1; n < P_IT; ++n) off = tap == n ? pvo[n] : off;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((cc + 1) & 1) * P_BYTES + piece * 8 * ROWB), 16, off, (cc + 1) * 128, 0, 0);
+                issued += 1;
             }
-#pragma unroll
-            for (int t = 0; t < TN; ++t)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(bb + t * 32 * ROWB + ((cb0 ^ (2 * ks)) << 4));
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
         }
+        issued_prev = issued;
+        const unsigned char* const pbuf = smem + (cc & 1) * P_BYTES;
+        const unsigned char* const bb = bbase + brd * B_BYTES;
+        const int toff = ty * PW + tx;
+        u32x4 fa[TM][4], fb[TN][4];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int pp = pp0[t] + toff;
+            const int a0 = pp * ROWB + ((kh ^ ((pp >> 1) & 7)) << 4);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(pbuf + (a0 ^ (ks << 5)));
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(bb + t * 32 * ROWB + ((cb0 ^ (2 * ks)) << 4));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
+        if (++tx == 3) { tx = 0; ++ty; }
+        if (++tap == 9) { tap = 0; ty = 0; tx = 0; ++cc; }
+        if (++tap2 == 9) { tap2 = 0; ++cc2; }
+        brd = brd == NB - 1 ? 0 : brd + 1;
+        bwr = bwr == NB - 1 ? 0 : bwr + 1;
     }
     } else {
     // ---- counter-phase schedule ----

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 3: the patch-resident 16-bit forward kernel (parity + timing), stress test, a few switches under lanes
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-OUT=gpurun_out/r05_4; mkdir -p $OUT
+OUT=gpurun_out/r05_5; mkdir -p $OUT
 export TMPDIR=/tmp
 summ() { python - "$1" <<'PY'
 import json,sys
