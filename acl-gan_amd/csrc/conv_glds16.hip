@@ -393,21 +393,22 @@ __global__ void __launch_bounds__((WM * WN + NP) * 64, NP ? 3 : (NBUF == 1 ? 4 :
 // by the PATCH row: a lane group's 16 rows are consecutive pixels of one image row (W a multiple of 32), so the reads stay conflict-free.
 // Same epilogue as conv_fwd16s (bias, activation, 16-bit stores, normalisation partials per 256-row tile).
 //
-// PP = 1 (the default form): the two waves of every SIMD work in COUNTER-PHASE (MI355X_MICROARCH.md "Two waves per SIMD"): the interval between
+// PP = 1 (a measured alternative, tuning fwd16_patch = 2; PP = 0, every wave in lockstep, is the default): the two waves of every SIMD work in COUNTER-PHASE (MI355X_MICROARCH.md "Two waves per SIMD"): the interval between
 // two s_barriers is a LOAD segment for one half of the workgroup (waves 0-3: 16 ds_read_b128 of its next fragments, then its share of
 // the LDS-DMA issues for the tile after next) and a COMPUTE segment (16 MFMAs on fragments already in registers) for the other half
-// (waves 4-7, one per SIMD), and the roles swap at every barrier -- in the PP = 0 form all eight waves copy, read and multiply in lockstep,
-// so a SIMD's matrix pipe idles through both of its waves' copy + read phases (measured: 48 us, 0.32 of the MFMA roof; PP = 1: see
-// profiles/r05_experiments.md section 3).  Three weight buffers (a tile is overwritten two intervals after its last reader), copies are
+// (waves 4-7, one per SIMD), and the roles swap at every barrier.  Measured: 50 us against 47 - 48 us for the lockstep form -- the MFMAs are
+// not what the kernel waits for (profiles/r05_fwd16p_ablation.txt: without its MFMAs the kernel takes the same 50 us; without fragment reads
+// AND copies 41 us; with none of the three 20 us = launch + prologue + epilogue + the barriers), see profiles/r05_experiments.md section 3.  Three weight buffers (a tile is overwritten two intervals after its last reader), copies are
 // waited for at the end of the issuing wave's next COMPUTE segment: a full segment of latency cover, no wait in front of a read.
 constexpr int PATCH_ROWS = 400;      // >= (256 / W + 2) * (W + 2) for W = 64 (396) and W = 32 (340)
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); WG_BARRIER(); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <class T, int WN, int TN, int PP>
+// ABL (measurement builds only, results are wrong): 1 = no MFMAs, 2 = no fragment reads in the loop, 4 = no copies in the loop
+template <class T, int WN, int TN, int PP, int ABL = 0>
 __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = 2, WM = 4, NW = WM * WN, NT = NW * 64, BM = WM * 64, BN = WN * TN * 32;
     static_assert(NW == 8, "eight waves");
-    constexpr int NB = 3;                                      // weight buffers: a tile is overwritten two k-tiles after its last reader
+    constexpr int NB = PP ? 3 : 2;                             // weight buffers
     constexpr int P_BYTES = PATCH_ROWS * ROWB, B_BYTES = BN * ROWB;
     constexpr int P_IT = (PATCH_ROWS / 8 + NW - 1) / NW;      // patch pieces (8 rows = 1 KB) per wave: 7
     constexpr int B_IT = BN / 8 / NW;                          // weight pieces per wave and k-tile: 2
@@ -481,65 +482,45 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
     const unsigned char* const bbase = sB + (wn * TN * 32 + l31) * ROWB;
 
     if constexpr (PP == 0) {
-    // ---- lockstep schedule, weight tiles TWO k-tiles ahead ----
-    // k-tile kt: wait until everything but the copies issued in k-tile kt-1 (tile kt+1, a patch piece) has landed -> tile kt is in LDS;
-    // barrier (every wave has it, every wave is done reading tile kt-1); issue tile kt+2 into the buffer of tile kt-1; multiply tile kt.
-    // A copy has two full k-tiles to land (one in the two-buffer form: under the load of 256 workgroups copying in bursts behind the same
-    // barrier an LDS-DMA copy takes ~1 us issue -> landed, longer than a k-tile's MFMAs -- profiles/r05_experiments.md section 3).
+    // ---- lockstep schedule (the default): every wave copies, reads and multiplies in the same k-tile; two weight buffers, one barrier per k-tile ----
+    // (measured alternatives, profiles/r05_experiments.md section 3: three weight buffers with the copies two k-tiles ahead 53 us; the
+    //  counter-phase schedule below 50 us; this one 47 - 48 us)
+    // prologue: the whole first patch and the first weight tile
 #pragma unroll
     for (int n = 0; n < P_IT; ++n) issue_p(n, 0, 0);
     issue_b(0, 0, 0);
-    issue_b(1, 0, 1);
-    int tap = 0, cc = 0, tap2 = 2, cc2 = 0, brd = 0, bwr = 2, ty = 0, tx = 0;
-    int issued_prev = B_IT;                          // copies of the newest tile in flight (tile 1): the wait leaves exactly those outstanding
-    for (int kt = 0; kt < nk; ++kt) {
-        if (issued_prev >= B_IT + 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(B_IT + 1));
-        else if (issued_prev == B_IT) __builtin_amdgcn_s_waitcnt(vmcnt_imm(B_IT));
-        else if (issued_prev == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(1));
-        else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-        __builtin_amdgcn_sched_barrier(0);
-        WG_BARRIER();
-        __builtin_amdgcn_sched_barrier(0);
-        int issued = 0;
-        if (kt + 2 < nk) { issue_b(tap2, cc2, bwr); issued += B_IT; }
-        if (tap < P_IT && cc + 1 < cpt) {           // the next patch, one piece per wave and tap
-            const int piece = tap * NW + wave;
-            if (piece < npieces) {
-                int off = pvo[0];
-#pragma unroll
-                for (int n = 1; n < P_IT; ++n) off = tap == n ? pvo[n] : off;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((cc + 1) & 1) * P_BYTES + piece * 8 * ROWB), 16, off, (cc + 1) * 128, 0, 0);
-                issued += 1;
-            }
-        }
-        issued_prev = issued;
+    int kt = 0;
+    for (int cc = 0; cc < cpt; ++cc) {
         const unsigned char* const pbuf = smem + (cc & 1) * P_BYTES;
-        const unsigned char* const bb = bbase + brd * B_BYTES;
-        const int toff = ty * PW + tx;
-        u32x4 fa[TM][4], fb[TN][4];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            const int pp = pp0[t] + toff;
-            const int a0 = pp * ROWB + ((kh ^ ((pp >> 1) & 7)) << 4);
+        for (int tap = 0; tap < 9; ++tap, ++kt) {
+            const int cur = kt & 1;
+            DMA_SYNCTHREADS();                     // every copy issued so far has landed, for every wave; the other buffers are free
+            if (kt + 1 < nk) { if (tap < 8) issue_b(tap + 1, cc, cur ^ 1); else issue_b(0, cc + 1, cur ^ 1); }
+            if (tap < P_IT && cc + 1 < cpt) issue_p(tap, cc + 1, (cc + 1) & 1);      // the next patch, one piece per tap
+            const int toff = (tap / 3) * PW + (tap % 3);
+            const unsigned char* const bb = bbase + cur * B_BYTES;
+            u32x4 fa[TM][4], fb[TN][4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(pbuf + (a0 ^ (ks << 5)));
+            for (int t = 0; t < TM; ++t) {
+                const int pp = pp0[t] + toff;
+                const int a0 = pp * ROWB + ((kh ^ ((pp >> 1) & 7)) << 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[t][ks] = *reinterpret_cast<const u32x4*>(pbuf + (a0 ^ (ks << 5)));
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(bb + t * 32 * ROWB + ((cb0 ^ (2 * ks)) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
         }
-#pragma unroll
-        for (int t = 0; t < TN; ++t)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(bb + t * 32 * ROWB + ((cb0 ^ (2 * ks)) << 4));
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
-        if (++tx == 3) { tx = 0; ++ty; }
-        if (++tap == 9) { tap = 0; ty = 0; tx = 0; ++cc; }
-        if (++tap2 == 9) { tap2 = 0; ++cc2; }
-        brd = brd == NB - 1 ? 0 : brd + 1;
-        bwr = bwr == NB - 1 ? 0 : bwr + 1;
     }
+
     } else {
     // ---- counter-phase schedule ----
     // intervals I0, I1, ... between consecutive barriers:   half 0: LOAD(0) COMPUTE(0) LOAD(1) COMPUTE(1) ...
@@ -559,12 +540,13 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
     int tap2 = 2, cc2 = 0;                          // tile kt + 2
     int brd = 0, bwr = 2;                           // weight buffer of tile kt / of tile kt + 2
     int ty = 0, tx = 0;                             // tap = 3 ty + tx
+    u32x4 fa[TM][4], fb[TN][4];
     for (int kt = 0; kt < nk; ++kt) {
         // ---- LOAD(kt): fragments first, copies last (nothing in front of the reads that could wait for a copy issued here) ----
         const unsigned char* const pbuf = smem + (cc & 1) * P_BYTES;
         const unsigned char* const bb = bbase + brd * B_BYTES;
         const int toff = ty * PW + tx;
-        u32x4 fa[TM][4], fb[TN][4];
+        if ((ABL & 2) == 0 || kt == 0) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int pp = pp0[t] + toff;
@@ -576,8 +558,9 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
         for (int t = 0; t < TN; ++t)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fb[t][ks] = *reinterpret_cast<const u32x4*>(bb + t * 32 * ROWB + ((cb0 ^ (2 * ks)) << 4));
-        if (kt + 2 < nk) issue_b(tap2, cc2, bwr);
-        if (tap < P_IT && cc + 1 < cpt) {           // the next patch, one piece per wave and tap
+        }
+        if ((ABL & 4) == 0 && kt + 2 < nk) issue_b(tap2, cc2, bwr);
+        if ((ABL & 4) == 0 && tap < P_IT && cc + 1 < cpt) {           // the next patch, one piece per wave and tap
             const int piece = tap * NW + wave;
             if (piece < npieces) {
                 int off = pvo[0];
@@ -588,12 +571,17 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
         }
         PP_BARRIER();
         // ---- COMPUTE(kt) ----
+        if constexpr ((ABL & 1) == 0) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(fa[i][ks], fb[j][ks], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { acc[0][0][ks] += __builtin_bit_cast(float, fa[0][ks][0] ^ fb[0][ks][1] ^ fa[1][ks][2] ^ fb[1][ks][3]); }
+        }
         __builtin_amdgcn_sched_barrier(0);          // (the wait stays BEHIND the MFMAs: hoisted to the head of the segment it would stall them)
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));   // the copies of LOAD(kt) have had this whole segment to land
         PP_BARRIER();
@@ -667,7 +655,7 @@ __global__ void __launch_bounds__(512, 1) conv_fwd16p_kernel(FwdSP p) {
 std::atomic<int> g_fwd16_patch{-1};
 int fwd16_patch_mode() {
     int v = g_fwd16_patch.load();
-    if (v < 0) { const char* e = getenv("ACLGAN_FWD16_PATCH"); v = e ? atoi(e) : 1; if (v < 0 || v > 2) v = 1; g_fwd16_patch.store(v); }
+    if (v < 0) { const char* e = getenv("ACLGAN_FWD16_PATCH"); v = e ? atoi(e) : 1; if (v < 0 || (v & 15) > 2) v = 1; g_fwd16_patch.store(v); }
     return v;
 }
 bool fwd16p_shape_ok(const ConvGeom& g) {
@@ -707,8 +695,18 @@ template <class T>
 int launch_fwd16s(const ConvGeom& g, FwdSP p, hipStream_t st) {
     if (fwd16_patch_mode() && fwd16p_shape_ok(g)) {      // 3x3 ResBlock shapes: the input patch stays in LDS for all nine taps
         p.tiles_n = g.Co / 128; p.nwg = (g.M / 256) * p.tiles_n;
-        if (fwd16_patch_mode() == 2) hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 0>), dim3(p.nwg), dim3(512), 0, st, p);      // lockstep form (measurement)
-        else hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1>), dim3(p.nwg), dim3(512), 0, st, p);
+#ifdef ACLGAN_FWD16P_ABLATION
+        const int abl = fwd16_patch_mode() >> 4;
+        if (abl == 1) { hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1, 1>), dim3(p.nwg), dim3(512), 0, st, p); ACL_CHECK_LAUNCH("abl"); return ACLGAN_OK; }
+        if (abl == 2) { hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1, 2>), dim3(p.nwg), dim3(512), 0, st, p); ACL_CHECK_LAUNCH("abl"); return ACLGAN_OK; }
+        if (abl == 4) { hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1, 4>), dim3(p.nwg), dim3(512), 0, st, p); ACL_CHECK_LAUNCH("abl"); return ACLGAN_OK; }
+        if (abl == 6) { hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1, 6>), dim3(p.nwg), dim3(512), 0, st, p); ACL_CHECK_LAUNCH("abl"); return ACLGAN_OK; }
+        if (abl == 7) { hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1, 7>), dim3(p.nwg), dim3(512), 0, st, p); ACL_CHECK_LAUNCH("abl"); return ACLGAN_OK; }
+        if (abl == 5) { hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1, 5>), dim3(p.nwg), dim3(512), 0, st, p); ACL_CHECK_LAUNCH("abl"); return ACLGAN_OK; }
+        if (abl == 3) { hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1, 3>), dim3(p.nwg), dim3(512), 0, st, p); ACL_CHECK_LAUNCH("abl"); return ACLGAN_OK; }
+#endif
+        if ((fwd16_patch_mode() & 15) == 2) hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 1>), dim3(p.nwg), dim3(512), 0, st, p);      // counter-phase form (measured alternative)
+        else hipLaunchKernelGGL((conv_fwd16p_kernel<T, 2, 2, 0>), dim3(p.nwg), dim3(512), 0, st, p);
         ACL_CHECK_LAUNCH("conv_fwd16p_kernel");
         return ACLGAN_OK;
     }
@@ -1178,7 +1176,7 @@ int set_dgrad16s_direct(int v) {
     return g_dgrad_direct.exchange(v ? 1 : 0);
 }
 // tuning knob "fwd16_patch": 1 = the 3x3 stride-1 layers it fits run on conv_fwd16p_kernel (input patch resident in LDS), 0 = on conv_fwd16s
-int set_fwd16_patch(int v) { const int old = fwd16_patch_mode(); g_fwd16_patch.store((v < 0 || v > 2) ? 1 : v); return old; }
+int set_fwd16_patch(int v) { const int old = fwd16_patch_mode(); g_fwd16_patch.store((v < 0 || (v & 15) > 2) ? 1 : v); return old; }
 // tuning / test knob behind aclgan_set_tuning("glds_tile", v): same values as ACLGAN_GLDS_TILE; returns the previous value
 int set_glds_tile(int v) {
     if (g_tile_force.load() < 0) glds_tile(1, 1);

@@ -314,7 +314,8 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
  * one-kernel Winograd weight gradient (csrc/conv_wino_wgrad_fused.hip) wherever the shape is eligible (W a multiple of 16, H of 4, Cout of 64,
  * Cin of 32).
  * key "fwd16_patch" (round 5): 1 (default) = the 3x3 stride-1 layers on 32- / 64-pixel-wide maps (the ResBlock convolutions) take
- * conv_fwd16p_kernel (csrc/conv_glds16.hip: the reflect-padded input patch of a 256-pixel tile stays in LDS for all nine taps), 0 = conv_fwd16s.
+ * conv_fwd16p_kernel (csrc/conv_glds16.hip: the reflect-padded input patch of a 256-pixel tile stays in LDS for all nine taps; 2 = its
+ * counter-phase schedule, a measured alternative), 0 = conv_fwd16s.
  * key "lanes" (round 5): 1 .. 4 HIP streams the independent branches of an update are spread over (the two translation directions,
  * the reconstruction decodes, the discriminators and their scales: reference trainer.py:103-139, 258-286; csrc/engine.hip "Lanes");
  * 1 = one queue (the round-4 plan), default 3 (ACLGAN_LANES).  Results do not depend on it.  key "u_batch" (round 5): 1 (default) =

@@ -1,5 +1,5 @@
 """The ResBlock convolution of the 16-bit path (8 x 64 x 64 x 256 -> 256, 3 x 3, 16-bit activations in HBM) a few times, for rocprofv3:
-    python scripts/probe_fwd16.py [bf16|fp16] [patch mode: 0 conv_fwd16s | 1 patch kernel, counter-phase | 2 patch kernel, lockstep] [B]"""
+    python scripts/probe_fwd16.py [bf16|fp16] [patch mode: 0 conv_fwd16s | 1 patch kernel, lockstep (default) | 2 patch kernel, counter-phase] [B]"""
 import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import aclgan_amd  # noqa

@@ -159,7 +159,7 @@ def test_conv_fwd16p_patch_kernel(L, case, dt):
     prev = C.c_int()
     L.check(L.lib.aclgan_tuning(b"fwd16_patch", 1, C.byref(prev)), "tuning")
     try:
-        for mode in (1, 2, 0):      # 1: the two waves of a SIMD in counter-phase (default), 2: all waves in lockstep, 0: conv_fwd16s
+        for mode in (1, 2, 0):      # 1: all waves in lockstep (default), 2: the two waves of a SIMD in counter-phase, 0: conv_fwd16s
             L.check(L.lib.aclgan_tuning(b"fwd16_patch", mode, None), "tuning")
             chunk = L.lib.aclgan_conv2d_fwd16s_stats_chunk(C.byref(d))
             y32 = torch.full((B, Hi, Wi, Co), float("nan"), device="cuda")
