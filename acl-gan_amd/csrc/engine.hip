@@ -135,8 +135,12 @@ struct StreamPool {
             hipError_t e = hipSuccess;
             static int prio = -1;      // ACLGAN_SIDE_PRIO=1: the parameter-gradient stream at the highest priority the device offers (measured neutral, round 4)
             if (prio < 0) { const char* pe = getenv("ACLGAN_SIDE_PRIO"); prio = pe ? atoi(pe) : 0; }
+            // ACLGAN_LANE_PRIO=-1: lanes 1.. at the LOWEST priority (lane 0, the caller's stream, carries the chain everything waits for)
+            static int lprio = -2;
+            if (lprio == -2) { const char* pe = getenv("ACLGAN_LANE_PRIO"); lprio = pe ? atoi(pe) : 0; }
             int lo = 0, hi = 0;
             if (i == 0 && prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) e = hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, prio > 0 ? hi : lo);
+            else if (i > 0 && lprio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) e = hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, lprio > 0 ? hi : lo);
             else e = hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking);
             if (e != hipSuccess) { s[i] = nullptr; return hip_fail(e, "stream pool"); }
         }
