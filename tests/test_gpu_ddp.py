@@ -317,5 +317,10 @@ def test_train_py_two_ranks_share_one_gpu(tmp_path):
                         "--synthetic", "--max_iter", "3"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     ck = os.path.join(tmp_path, "outputs", "tiny", "checkpoints")
-    assert sorted(os.listdir(ck)) == ["dis_00000002.pt", "dis_00000003.pt", "gen_00000002.pt", "gen_00000003.pt", "optimizer.pt"]
+    # (loop_state.json, round 5: the run's seed and pass index next to the checkpoints, so that a restart continues the data order)
+    assert sorted(os.listdir(ck)) == ["dis_00000002.pt", "dis_00000003.pt", "gen_00000002.pt", "gen_00000003.pt", "loop_state.json", "optimizer.pt"]
+    import json
+    with open(os.path.join(ck, "loop_state.json")) as f:
+        state = json.load(f)
+    assert state["iterations"] == 3 and state["seed"] == 0 and state["epoch"] == 0, state
     assert r.stdout.count("Iteration: 00000001/") == 1 and r.stdout.count("Finish training") == 1      # rank 0 alone prints
