@@ -281,9 +281,10 @@ struct aclgan_ctx {
     }
     int side_fork() {       // the side stream may start once everything enqueued on the current lane so far is done
         if (dry) return ACLGAN_OK;
-        if (!st2) {
-            int rc = aclgan::StreamPool::of_device().get(0, &st2);
+        if (!st2) {      // (entry points that do not go through lanes_begin)
+            int rc = aclgan::StreamPool::of_device().get(0, &st2_pool);
             if (rc) return rc;
+            st2 = st2_pool;
         }
         if (!ev_fork) {
             hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
@@ -333,15 +334,33 @@ struct aclgan_ctx {
     hipStream_t lane_stream(int l) const { return l == 0 ? st0 : lane_st[l]; }
     int nck(int l) const { return (int)lane_evs[l].size(); }
     // lanes of this step; streams are created on first use and live as long as the context
+    hipStream_t st2_pool = nullptr, st2_private = nullptr;
+    static bool nck_created_private_ok() { return true; }      // (the private stream is created on the first, eager, update: not inside a capture)
     int lanes_begin(int want) {
         nlanes = std::max(1, std::min(want, (int)MAXL));
         if (!side_enabled()) nlanes = 1;             // parameter gradients need their own ordered stream once there is more than one lane
+        // Under stream capture (aclgan_Trainer(hip_graph=True): torch.cuda.graph around the update) the update runs as in round 4: one lane
+        // and a parameter-gradient stream PRIVATE to this context.  Capturing the lanes of the process-wide pool crashed hipStreamEndCapture
+        // on this ROCm (round 5, tests/test_gpu_graph.py: gen_update with three pooled lanes); a replayed graph gained nothing from a second
+        // queue in any regime measured, so the capture keeps the plan that is known to work.
+        bool capturing = false;
+        if (!dry) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) capturing = true;
+            else (void)hipGetLastError();
+        }
+        if (capturing) nlanes = 1;
         cur_lane = 0; st0 = st;
         for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; lane_dirty[l] = false; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
         ev_next = 0;
         if (dry) return ACLGAN_OK;
         // (parameter-gradient stream first, then the lanes: with the caller's stream that is one hardware queue each up to 3 lanes)
-        if (side_enabled() && !st2) { int rc = aclgan::StreamPool::of_device().get(0, &st2); if (rc) return rc; }
+        if (side_enabled() && !st2_pool) { int rc = aclgan::StreamPool::of_device().get(0, &st2_pool); if (rc) return rc; }
+        if (side_enabled() && !st2_private && (capturing || nck_created_private_ok())) {
+            hipError_t e = hipStreamCreateWithFlags(&st2_private, hipStreamNonBlocking);
+            if (e != hipSuccess) return aclgan::hip_fail(e, "private side stream");
+        }
+        st2 = capturing ? st2_private : st2_pool;
         for (int l = 1; l < nlanes; ++l)
             if (!lane_st[l]) { int rc = aclgan::StreamPool::of_device().get(l, &lane_st[l]); if (rc) return rc; }
         return ACLGAN_OK;
@@ -454,7 +473,8 @@ struct aclgan_ctx {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
-        // (the streams belong to the process-wide pool)
+        if (st2_private) (void)hipStreamDestroy(st2_private);
+        // (the other streams belong to the process-wide pool)
     }
     void reset_step() {
         for (Act* a : acts) delete a;

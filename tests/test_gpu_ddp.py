@@ -126,7 +126,7 @@ def test_bench_eight_ranks_control_flow_and_overlap_fallback():
     assert out["config"]["grad_allreduce"] == "after backward" and out["config"]["replicas_identical"] is True
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("lanes", [1, 3])
 def test_bucket_callback_fires_after_the_last_writer(lanes):
     """(round 5: under the branch-parallel replay as well -- `lanes` streams carry the backward closures, the parameter gradients are on
     their own stream; before a bucket is handed out, lane 0 = the caller's stream has joined all of them: csrc/engine.hip run_tape.)

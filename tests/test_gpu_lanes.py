@@ -69,10 +69,9 @@ def test_lane_count_does_not_change_a_bit(L, dtype):
     prev = _tune(L, b"lanes", 1)
     try:
         one = _step(T, cfg, nets, x_a, x_b, z, dtype, True)
-        for lanes in (2, 3, 4):
+        for lanes in (2, 3, 4, 3):        # (the default, 3, twice: a race is not obliged to show on the first try)
             _tune(L, b"lanes", lanes)
-            for rep in range(2):          # (a race is not obliged to show on the first try)
-                _same(one, _step(T, cfg, nets, x_a, x_b, z, dtype, True))
+            _same(one, _step(T, cfg, nets, x_a, x_b, z, dtype, True))
     finally:
         _tune(L, b"lanes", prev)
         L.check(L.lib.aclgan_set_deterministic(prev_det))

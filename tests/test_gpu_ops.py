@@ -220,7 +220,7 @@ def test_winograd_fused_kernels_repeat_launch_stress(L, case):
     fwd_scr = torch.empty(L.lib.aclgan_conv2d_fwd_scratch_bytes(C.byref(d)) // 4 + 16, device="cuda")
     dg_scr = torch.empty(L.lib.aclgan_conv2d_dgrad_scratch_bytes(C.byref(dn)) // 4 + 16, device="cuda")
     wg_scr = torch.empty(L.lib.aclgan_conv2d_wgrad_scratch_bytes(C.byref(dn)) // 4 + 16, device="cuda")
-    N = 1500
+    N = 800
     busy = torch.cuda.Stream()
     noise = torch.randn(1 << 24, device="cuda")
     old_f = L.lib.aclgan_set_tuning(b"wino_fused", 2); old_w = L.lib.aclgan_set_tuning(b"wino_wgrad_fused", 2)
