@@ -62,7 +62,7 @@ def male2female_config():
 BASELINE_BATCH = {"male2female": 8, "selfie2anime": 8, "glasses_removal": 4}
 
 
-TRAFFIC_FILE = "profiles/r04_step_traffic.json"
+TRAFFIC_FILE = "profiles/r05_step_traffic.json"
 
 
 def library_md5():
@@ -76,7 +76,7 @@ def library_md5():
 
 def step_traffic(dtype, S, B, launches_per_step=None):
     """memory-side bytes of ONE step from the committed PMC passes (rocprofv3 --pmc cannot run inside the timed process):
-    profiles/r04_step_traffic.json, written by scripts/step_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    profiles/r05_step_traffic.json, written by scripts/step_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
     runs of scripts/probe_step.py = sum over every kernel of one dis_update + gen_update of 2 x FETCH_SIZE (gfx950 correction,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE.  The entry records the build it was measured on (md5 of libaclgan_hip.so, kernel
     launches per step): when either differs from the library that is running, the figure is reported with stale = True.
@@ -198,7 +198,7 @@ def dominant_kernel_probe(L, dtype, reps=20):
         alg_bytes = 4.0 * (x.numel() + y.numel() + 36 * Cc * Cc)      # x read, y written, U read: what the launch must move
         pmc = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc_wino_fused.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r05_pmc_wino_fused.json")) as f:
                 pmc = json.load(f)
         except Exception:   # noqa: BLE001
             pass
@@ -210,7 +210,7 @@ def dominant_kernel_probe(L, dtype, reps=20):
                "algorithmic_frac": round(flop_direct / ms / 1e9 / PEAK[dtype], 4),
                "algorithmic_bytes": alg_bytes,
                "traffic": None if not pmc else pmc.get("bytes_per_launch"),
-               "traffic_source": None if not pmc else "profiles/r04_pmc_wino_fused.json (2 x FETCH_SIZE + WRITE_SIZE of this launch)",
+               "traffic_source": None if not pmc else "profiles/r05_pmc_wino_fused.json (2 x FETCH_SIZE + WRITE_SIZE of this launch)",
                "traffic_stale": None if not pmc else bool(pmc.get("lib_md5") != library_md5()),
                "replaces": "round 3: wino_input + 36-slice GEMM launch + wino_output = 157 us and 469 MB of memory-side traffic per convolution"}
         return out

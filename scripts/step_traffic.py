@@ -7,7 +7,7 @@
 
 Sums the counter over every kernel the library launched (torch's own init / fill kernels excluded), divides by the number of steps,
 applies the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read: x2) and merges
-{key: {"bytes_per_step", "fetch_bytes", "write_bytes", ...}} into out.json (default profiles/r04_step_traffic.json).  Counter unit: KiB.
+{key: {"bytes_per_step", "fetch_bytes", "write_bytes", ...}} into out.json (default profiles/r05_step_traffic.json).  Counter unit: KiB.
 The entry is bound to the build it was measured on: md5 of acl-gan_amd/libaclgan_hip.so, the library's own launch count per step
 (scripts/probe_step.py writes it to $PROBE_STEP_JSON) and the commit ($ACLGAN_HEAD: .git does not travel to the GPU box); bench.py compares
 them with the running library and reports traffic_stale on a mismatch."""
@@ -33,7 +33,7 @@ def load(dbp, counter):
 
 def main():
     fdb, wdb, steps, key = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_step_traffic.json")
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_step_traffic.json")
     summary = sys.argv[6] if len(sys.argv) > 6 else None
     f, w = load(fdb, "FETCH_SIZE"), load(wdb, "WRITE_SIZE")
     fetch = 2.0 * 1024.0 * sum(v[1] for v in f.values()) / steps      # gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x
