@@ -80,6 +80,7 @@ SIGNATURES = {
     "aclgan_last_error": (C.c_char_p, []),
     "aclgan_ctx_create": (ci, [C.POINTER(Arch), C.POINTER(vp)]),
     "aclgan_ctx_destroy": (None, [vp]),
+    "aclgan_ctx_enable_capture": (ci, [vp]),
     "aclgan_group_numel": (i64, [vp, ci]),
     "aclgan_tensor_count": (ci, [vp, ci]),
     "aclgan_tensor_info": (ci, [vp, ci, ci, C.c_char_p, ci, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci)]),

@@ -335,7 +335,15 @@ struct aclgan_ctx {
     int nck(int l) const { return (int)lane_evs[l].size(); }
     // lanes of this step; streams are created on first use and live as long as the context
     hipStream_t st2_pool = nullptr, st2_private = nullptr;
-    static bool nck_created_private_ok() { return true; }      // (the private stream is created on the first, eager, update: not inside a capture)
+    // The private stream exists only for contexts that capture (aclgan_ctx_enable_capture creates it outside any capture; a capture that
+    // comes without that call creates it on the spot): an extra stream, even an idle one, shifts HIP's stream -> hardware-queue placement --
+    // creating it for every context cost the eager step 3 ms (89.1 against 86.2 ms, profiles/r05_experiments.md section 2).
+    int make_private_side() {
+        if (st2_private) return ACLGAN_OK;
+        hipError_t e = hipStreamCreateWithFlags(&st2_private, hipStreamNonBlocking);
+        if (e != hipSuccess) return aclgan::hip_fail(e, "private side stream");
+        return ACLGAN_OK;
+    }
     int lanes_begin(int want) {
         nlanes = std::max(1, std::min(want, (int)MAXL));
         if (!side_enabled()) nlanes = 1;             // parameter gradients need their own ordered stream once there is more than one lane
@@ -356,10 +364,7 @@ struct aclgan_ctx {
         if (dry) return ACLGAN_OK;
         // (parameter-gradient stream first, then the lanes: with the caller's stream that is one hardware queue each up to 3 lanes)
         if (side_enabled() && !st2_pool) { int rc = aclgan::StreamPool::of_device().get(0, &st2_pool); if (rc) return rc; }
-        if (side_enabled() && !st2_private && (capturing || nck_created_private_ok())) {
-            hipError_t e = hipStreamCreateWithFlags(&st2_private, hipStreamNonBlocking);
-            if (e != hipSuccess) return aclgan::hip_fail(e, "private side stream");
-        }
+        if (side_enabled() && capturing) { int rc = make_private_side(); if (rc) return rc; }
         st2 = capturing ? st2_private : st2_pool;
         for (int l = 1; l < nlanes; ++l)
             if (!lane_st[l]) { int rc = aclgan::StreamPool::of_device().get(l, &lane_st[l]); if (rc) return rc; }
@@ -1552,6 +1557,11 @@ int aclgan_ctx_create(const aclgan_arch* arch, aclgan_ctx** out) {
 }
 
 void aclgan_ctx_destroy(aclgan_ctx* ctx) { delete ctx; }
+
+int aclgan_ctx_enable_capture(aclgan_ctx* ctx) {
+    ACL_REQUIRE(ctx, "null ctx");
+    return ctx->make_private_side();
+}
 
 int aclgan_set_compute_dtype(aclgan_ctx* ctx, int dtype) {
     ACL_REQUIRE(ctx && dtype >= ACLGAN_DTYPE_FP32 && dtype <= ACLGAN_DTYPE_FP16, "bad ctx / dtype %d", dtype);

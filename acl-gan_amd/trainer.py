@@ -208,6 +208,9 @@ class aclgan_Trainer:
         self._ctx = C.c_void_p()
         L.check(L.lib.aclgan_ctx_create(C.byref(self.arch), C.byref(self._ctx)), "ctx_create")
         L.check(L.lib.aclgan_set_compute_dtype(self._ctx, L.DTYPE[self.compute_dtype]), "set_compute_dtype")
+        if self.hip_graph:      # (a captured update runs on one lane with a parameter-gradient stream of its own: created here, outside any capture)
+            with torch.cuda.device(self.device):
+                L.check(L.lib.aclgan_ctx_enable_capture(self._ctx), "ctx_enable_capture")
         self.style_dim = hp["gen"]["style_dim"]
         self.alpha = hp["alpha"]
         self.focus_lam = hp["focus_loss"]

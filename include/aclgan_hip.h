@@ -151,6 +151,11 @@ int aclgan_get_deterministic(void);
 /* ---- context: replaces aclgan_Trainer.__init__ network construction (trainer.py:15-23) ---- */
 int aclgan_ctx_create(const aclgan_arch* arch, aclgan_ctx** out);
 void aclgan_ctx_destroy(aclgan_ctx* ctx);
+/* Call once, OUTSIDE any stream capture, on a context whose updates will be captured into a HIP graph (torch.cuda.graph around
+ * aclgan_gen_update / aclgan_dis_update): creates the context-private parameter-gradient stream a captured update runs its weight gradients
+ * on (a captured update uses one lane; the process-wide lane streams are not captured).  Contexts that never capture should not call it:
+ * every additional stream shifts HIP's stream -> hardware-queue placement (measured: 3 ms on the eager fp32 step). */
+int aclgan_ctx_enable_capture(aclgan_ctx* ctx);
 
 /* flat parameter buffers.  Tensors are laid out back to back in the reference's
  * `parameters()` order (gen: gen_AB then gen_BA; dis: dis_A, dis_B, dis_2 -- trainer.py:37-38). */

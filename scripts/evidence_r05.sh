@@ -43,7 +43,7 @@ if has probewg; then (timeout 300 python scripts/probe_wgrad_fused.py 2>&1 | gre
 if has benchold; then ACLGAN_WINO_FUSED=0 $B > $O/bench_256_fp32_three_launch_winograd.json 2>/dev/null; summ $O/bench_256_fp32_three_launch_winograd.json | tee -a $O/progress.log; fi
 trace() {   # tag, bench args (env passes through)
     rm -rf /tmp/prof_$1
-    timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-launch-floor $2 > $O/prof_$1.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-launch-floor --no-other-configs $2 > $O/prof_$1.log 2>&1
     DB=$(find /tmp/prof_$1 -name "*.db" | head -1)
     python scripts/rocpd_stats.py $DB > $O/kernel_stats_$1.txt 2>&1
     python scripts/rocpd_bygrid.py $DB 6 "" 100000 > $O/by_grid_$1.txt 2>&1      # (round 5: the FULL table, tail included)
@@ -103,7 +103,7 @@ if has pmcwgrad; then
 fi
 if has roctx; then
     rm -rf /tmp/prof_roctx
-    ACLGAN_ROCTX=1 ACLGAN_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --marker-trace -d /tmp/prof_roctx -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-launch-floor > $O/prof_roctx.log 2>&1
+    ACLGAN_ROCTX=1 ACLGAN_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --marker-trace -d /tmp/prof_roctx -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-launch-floor --no-other-configs > $O/prof_roctx.log 2>&1
     DB=$(find /tmp/prof_roctx -name "*.db" | head -1)
     python scripts/rocpd_schema.py $DB > $O/roctx_schema.txt 2>&1
     python scripts/rocpd_bypass.py $DB > $O/kernel_time_by_pass.txt 2>&1
