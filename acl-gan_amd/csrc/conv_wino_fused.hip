@@ -240,6 +240,16 @@ __device__ __forceinline__ void wf_wave(const WfP& p, char* smem, const int lane
     };
     // 18 accumulator tiles = 288 registers: 16 tiles fill the 256 AGPRs; the MFMAs of the last two (fi = 8) are written in their VGPR
     // form by hand (the builtin would take the AGPR form for every tile and shuttle tiles between the two files on every iteration)
+    // Hazards of the hand-written form (the compiler neither inserts wait states nor s_nops inside an asm statement):
+    //   * its result registers are read next by (a) another `v_mfma` on the same accumulator -- back-to-back dependent MFMAs of one size are
+    //     interlocked by the hardware (SrcC forwarding), no software wait states -- and (b) VALU / LDS-store instructions of the epilogue, which
+    //     come after the K loop's last barrier and >= 18 independent MFMAs (64 cycles each) later: far beyond the 18-pass XDL write -> VALU read
+    //     requirement of the ISA;
+    //   * its A / B operands come from VALU results (the packed transform) or loads: both are ordinary "v" inputs, so the compiler's own
+    //     VALU-write -> MFMA-read handling (it sees the asm's inputs) and its s_waitcnt insertion for the loads apply;
+    //   * "+v" ties the accumulator in place; `volatile` keeps the statement's position relative to the sched_barriers of the loop.
+    // tests/test_gpu_ops.py::test_winograd_fused_kernels_repeat_launch_stress launches the kernel 800 times per shape next to a busy second
+    // stream and compares every result bitwise with the first (advisor, round 4).
     auto mfma1 = [&](int fi, int j, float a, float b) __attribute__((always_inline)) {
         if (fi == 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[fi][j]) : "v"(a), "v"(b));
         else acc[fi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[fi][j], 0, 0, 0);
