@@ -407,7 +407,11 @@ def main():
     losses_ok = all(map(lambda n: torch.isfinite(getattr(tr, n)).item(), ["loss_gen_total", "loss_dis_total"]))
     rccl_info = None
     if use_dist:
-        rccl_info = {"overlap_fallback": overlap_fallback, "log": rccl_log}
+        rccl_info = {"overlap_fallback": overlap_fallback, "log": rccl_log,
+                     # which queue a bucket's all-reduce is ordered after (csrc/engine.hip run_tape): ProcessGroupNCCL records its event on the
+                     # caller's current stream = lane 0, and the engine makes lane 0 wait for every lane and for the parameter-gradient
+                     # stream before it fires the bucket callback
+                     "collectives_ordered_after": "lane 0 (caller's stream) after it joined all lanes and the parameter-gradient stream"}
         try:
             if rccl_log and os.path.exists(rccl_log):
                 lines = open(rccl_log, errors="replace").read().splitlines()
