@@ -18,6 +18,11 @@ fp32 accumulation, fp32 master weights and Adam, fp16 with dynamic loss scaling.
 Timing: K steps bracketed by barrier + synchronize, max over ranks -> `value` / `ms_per_step` (the contract);
 per-step HIP events on the launch stream give `config.ms_per_step_median` (SURVEY.md 8d defines the median).
 
+config.other_configs (N = 1, headline workload only): after the timed region, 2 warm-up + 5 timed steps each of the other single-GPU shapes
+BASELINE.json names -- 512x512 fp32 B=4 (configs[3]) and the per-GPU shapes of the two 8-GPU rows, 256x256 bf16 B=8 (configs[2]) and fp16 B=32
+(configs[4]) -- so that the driver's own bench file carries them; they are not `value`.  config.lanes: HIP streams the independent branches of an
+update run on (csrc/engine.hip "Lanes"; --lanes N, default 3).
+
 Extra objects in the JSON line:
   roofline     MFMA-bound.  achieved = contract FLOPs (2.623 TFLOP per image at 256^2: NECESSARY conv+linear work of
                one dis+gen step) x images per step / event-timed step, against the matrix peak of the
