@@ -208,7 +208,13 @@ int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int 
 /* aclgan_Trainer.gen_update minus zero_grad/opt.step (trainer.py:92-169): forward of the whole
  * generator/discriminator graph, the 12 generator losses, backward into the GEN group's grad
  * buffer (accumulating; call aclgan_zero_grad first).  x_a, x_b: (B,3,H,W) NCHW fp32; z: device
- * (3,B,style_dim) = z_1,z_2,z_3 (trainer.py:99-101).  losses: device float[ACLGAN_L_COUNT]. */
+ * (3,B,style_dim) = z_1,z_2,z_3 (trainer.py:99-101).  losses: device float[ACLGAN_L_COUNT].
+ * Streams (round 5): the work is ordered after everything already enqueued on `stream` and complete, for `stream`, when the call's last
+ * enqueue is (a consumer ordered after `stream` sees the finished update) -- but inside the call independent branches of the update run on
+ * up to three more streams of a process-wide pool and the parameter gradients on a fourth ("lanes", aclgan_tuning "lanes"; 1 = `stream`
+ * only plus the parameter-gradient stream).  The calling thread's current HIP device must be the device `stream` belongs to (the pool is
+ * per device); two threads may step two contexts on one device concurrently (their work interleaves on the pooled streams, ordered by
+ * each update's own events), one context is used by one thread at a time.  On an error return every internal stream has been drained. */
 int aclgan_gen_update(aclgan_ctx* ctx, const float* x_a, const float* x_b, const float* z,
                       int B, int H, int W, const aclgan_hparams* hp, float* losses, void* stream);
 /* aclgan_Trainer.dis_update minus zero_grad/opt.step (trainer.py:249-292); grads into the DIS group */
