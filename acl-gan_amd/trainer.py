@@ -275,6 +275,10 @@ class aclgan_Trainer:
             self._lscale = torch.tensor([s0, 1.0 / s0, 0, 0, 0, 0, float(hp.get("loss_scale_growth_interval", 2000)), 0],
                                         dtype=torch.float32, device=self.device)
             L.check(L.lib.aclgan_bind_loss_scale(self._ctx, L.ptr(self._lscale)), "bind_loss_scale")
+        # the scale each group's gradient buffers carry: a device-side copy of the live scale taken when that group's update starts
+        # (grad_scale(grp)); the two groups are updated at different live scales whenever one of them overflowed in between
+        self._gscale = None if self._lscale is None else torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._last_grp = None
         self._setup_data_parallel()
 
     def __del__(self):
@@ -403,14 +407,22 @@ class aclgan_Trainer:
         v = self._lscale.cpu().tolist()
         return {"scale": v[0], "clean_updates": int(v[2]), "skipped_gen": int(v[4]), "skipped_dis": int(v[5])}
 
-    def grad_scale(self):
-        """the factor the gradient buffers carry: fp16 -- before the first update the initial loss scale, afterwards the scale the
-        LAST update ran with (slot 7 of the device state, recorded by aclgan_adam_step before it halves / doubles the live scale);
-        fp32 / bf16 -- 1"""
+    def grad_scale(self, grp=None):
+        """the factor a group's gradient buffers carry.  fp32 / bf16: 1.  fp16: the loss scale that group's last update ran with --
+        the generator's and the discriminators' buffers differ whenever an overflow halved (or a clean run doubled) the live scale
+        between the two updates.  grp: "gen" / "dis" (or GROUP_GEN / GROUP_DIS); None -> the group updated last.  A group that has not
+        been updated yet reports the live scale (its buffers are zero).  One device->host copy, only when asked."""
         if self._lscale is None:
             return 1.0
-        v = self._lscale.cpu().tolist()
-        return float(v[7]) if v[7] > 0 else float(v[0])
+        if grp is None:
+            grp = self._last_grp
+        elif isinstance(grp, str):
+            grp = {"gen": L.GROUP_GEN, "dis": L.GROUP_DIS}[grp]
+        live = float(self._lscale[0].item())
+        if grp is None:
+            return live
+        own = float(self._gscale[grp].item())
+        return own if own > 0 else live
 
     def _draw_z(self, B):
         # three draws from the CPU generator, in the reference's order (trainer.py:99-101); data-parallel ranks use
@@ -447,6 +459,9 @@ class aclgan_Trainer:
                 self._graphs = {}
             self._ensure_workspace(B, H, W)
             st = self._st()
+            if self._gscale is not None:      # fp16: this update's gradients carry the scale that is live NOW (stream-ordered copy, no sync)
+                self._gscale[grp:grp + 1].copy_(self._lscale[0:1])
+                self._last_grp = grp
             fn = L.lib.aclgan_gen_update if which == "gen" else L.lib.aclgan_dis_update
             if self.hip_graph and self._reducer is None and self._run_graph(which, grp, fn, x_a, x_b, zz, B, H, W, hpc):
                 pass        # zero_grad + update replayed from the captured graph

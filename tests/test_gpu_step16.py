@@ -398,8 +398,14 @@ def test_fp16_loss_scale_state_survives_a_checkpoint(T, tmp_path):
     tr.dis_update(x_a, x_b, cfg, z=z[:3])             # overflows: skipped, scale halves
     torch.cuda.synchronize()
     assert tr.loss_scale_state()["scale"] == 2.0 ** 39 and tr.grad_scale() == 2.0 ** 40      # the buffers of that update carry 2^40
+    assert tr.grad_scale("dis") == 2.0 ** 40 and tr.grad_scale("gen") == 2.0 ** 39           # (gen not updated yet: the live scale)
+    tr.gen_update(x_a, x_b, cfg, z=z[3:])              # runs at 2^39 (overflows again): per group, not one shared slot
+    torch.cuda.synchronize()
+    assert tr.grad_scale("gen") == 2.0 ** 39 and tr.grad_scale("dis") == 2.0 ** 40 and tr.grad_scale() == 2.0 ** 39
+    live = tr.loss_scale_state()["scale"]
+    assert live == 2.0 ** 38, live
     tr.save(str(tmp_path), 0)
     tr2 = T.aclgan_Trainer(cfg, compute_dtype="fp16")
     tr2.resume(str(tmp_path), cfg)
     a, b = tr.loss_scale_state(), tr2.loss_scale_state()
-    assert a == b and b["skipped_dis"] == 1 and b["scale"] == 2.0 ** 39, (a, b)
+    assert a == b and b["skipped_dis"] == 1 and b["skipped_gen"] == 1 and b["scale"] == live, (a, b)
