@@ -188,6 +188,17 @@ bool wino_wgrad_fused_ok(const ConvGeom& g);
 size_t wino_wgrad_fused_scratch_bytes(const ConvGeom& g);
 int wino_wgrad_fused(const ConvGeom& g, const float* x, const float* dy, float* dw, float* db, void* scratch, hipStream_t st);
 int wino_fused_up5_dgrad(int B, int Hi, int Wi, int Cin_, int Cout_, const float* dy, const float* Uf, float* dx, int Hf, int Wf, int accumulate, hipStream_t st);
+// Round 6: the 4x4 stride-2 reflect-pad-1 layers as four parity phases through the same kernel (conv_wino_fused.hip, "s2k4")
+bool wino_fused_s2k4_ok(int B, int Hi, int Wi, int Ci, int Co, int act, int dgrad);
+size_t wino_fused_s2k4_u_bytes(int Ci, int Co);
+int wino_fused_filter_s2k4(const float* w, float* Uf, int Co, int Ci, int dgrad, hipStream_t st);
+int wino_fused_s2k4_fwd(int B, int Hi, int Wi, int Ci, int Co, const float* x, const float* Uf, const float* bias, float* y, int act, float2* stats, hipStream_t st);
+int wino_fused_s2k4_dgrad(int B, int Hi, int Wi, int Ci, int Co, const float* dy, const float* Uf, float* dx, int accumulate, hipStream_t st);
+// ... and their conv-level wrappers (conv_wino.hip): which = 0 forward, 1 input gradient (interior of the padded grid; never in deterministic mode)
+bool conv_s2k4_wino_ok(const ConvGeom& g, int which);
+size_t conv_s2k4_wino_scratch_bytes(const ConvGeom& g);
+int conv_fwd_s2k4_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats = nullptr);
+int conv_dgrad_s2k4_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);
 // gemm_bf16x3.hip: fp32-accurate GEMM slices on the bf16 matrix cores from 3-plane (h, m, l) bf16 operands
 bool gemm_x3_shape_ok(int T, int K, int N);
 int gemm_slices_x3(const void* A3, size_t a_plane, const void* B3, size_t b_plane, float* C, int T, int K, int N, int nslices, int a_mod, hipStream_t st);

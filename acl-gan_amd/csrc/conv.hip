@@ -491,7 +491,8 @@ __global__ void conv_fold_kernel(FoldP f) {
 
 size_t conv_dgrad_scratch_bytes(const ConvGeom& g) {
     // padded-grid gradient (general path) or the merged phase weights (sub-pixel path), whichever is larger
-    return std::max(std::max((size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float), conv_up5_dgrad_scratch_bytes(g)), conv_wino_scratch_bytes(g));
+    return std::max(std::max((size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float), conv_up5_dgrad_scratch_bytes(g)),
+                    std::max(conv_wino_scratch_bytes(g), conv_s2k4_wino_scratch_bytes(g)));
 }
 
 template <int WM, int WN, int TM, int TN>

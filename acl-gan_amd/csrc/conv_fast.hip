@@ -528,6 +528,7 @@ int dgrad_fast_all(const ConvGeom& g, DgFP p, float* dxp, float* dx, int accumul
         if (rc != ACLGAN_EUNSUPPORTED) return rc;
         p.mode = 1;
         rc = (dxp && conv_wino_ok(g)) ? conv_dgrad_wino_interior(g, p.dy, p.w, dx, accumulate, dxp, st)   // interior: Winograd (zero pad, flipped w^T)
+             : (dxp && conv_s2k4_wino_ok(g, 1)) ? conv_dgrad_s2k4_wino_interior(g, p.dy, p.w, dx, accumulate, dxp, st)      // 4x4 stride 2: four parity phases
                                       : launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
         if (rc) return rc;
         if (g.p > 0 && deterministic()) {
@@ -1085,7 +1086,7 @@ size_t conv_fwd_fast_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled()) return 0;
     if (conv_wino_ok(g)) return conv_wino_scratch_bytes(g);
     if (up5_eligible(g)) return up5_merged_bytes(g) + ((fwd_partial_bytes(g, 2, BK) + 255) & ~(size_t)255) + conv_up5_wino_fwd_scratch_bytes(g);
-    return fwd_partial_bytes(g, 0, BK);
+    return std::max(fwd_partial_bytes(g, 0, BK), conv_s2k4_wino_scratch_bytes(g));
 }
 
 int conv_up5_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* keepV) {
@@ -1161,7 +1162,9 @@ int gemm_slices_f32(const float* A, const float* Bm, float* Cm, int T, int K, in
 int conv_fwd_stats_chunk(const ConvGeom& g) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("ACLGAN_NOSTATFUSE"); off = (e && atoi(e)) ? 1 : 0; }
-    return (!off && fast_enabled() && g.Ci % 16 == 0 && g.act == ACLGAN_ACT_NONE && conv_wino_ok(g)) ? 16 : 0;
+    if (off || !fast_enabled() || g.Ci % 16 != 0 || g.act != ACLGAN_ACT_NONE) return 0;
+    if (conv_wino_ok(g)) return 16;
+    return (g.Ho % 4 == 0 && g.Wo % 4 == 0 && conv_s2k4_wino_ok(g, 0)) ? 16 : 0;      // (round 6: the 4x4 stride-2 layers through the fused kernel)
 }
 // bytes of the Winograd input transform conv_fwd can leave behind for conv_wgrad (same path selection as conv_fwd / conv_wgrad)
 size_t conv_fwd_keep_bytes(const ConvGeom& g) {
@@ -1175,6 +1178,8 @@ size_t conv_fwd_keep_bytes(const ConvGeom& g) {
 int conv_fwd_fast(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch, float* stats, float* keepV) {
     if (!fast_enabled() || g.Ci % 16 != 0) return ACLGAN_EUNSUPPORTED;
     if (scratch && conv_wino_ok(g)) return conv_fwd_wino(g, x, w, bias, y, scratch, st, stats, keepV);   // 3x3 ResBlock convs: Winograd F(4x4,3x3)
+    if (scratch && !keepV && conv_s2k4_wino_ok(g, 0) && (!stats || (g.Ho % 4 == 0 && g.Wo % 4 == 0)))      // 4x4 stride-2 layers: four parity phases of the same kernel
+        return conv_fwd_s2k4_wino(g, x, w, bias, y, scratch, st, stats);
     if (stats || keepV) return ACLGAN_EUNSUPPORTED;
     FwdFP p;
     p.fsl = 0; p.fsx_mod = 0; p.fs_x = p.fs_w = p.fs_y = 0; p.w16 = nullptr; p.x16 = nullptr;

@@ -560,6 +560,7 @@ int set_wino_x3(int v) { const int old = wino_x3() ? 1 : 0; g_wino_x3.store(v ? 
 size_t conv_wino_u_bytes(const ConvGeom& g) {
     if (conv_wino_ok(g)) return align256((size_t)36 * g.Co * g.Ci * 6);
     if (conv_up5_wino_ok(g)) return align256((size_t)144 * g.Co * g.Ci * 6);
+    if (conv_s2k4_wino_ok(g, 0) || conv_s2k4_wino_ok(g, 1)) return align256(wino_fused_s2k4_u_bytes(g.Ci, g.Co));
     return 0;
 }
 size_t conv_wino_scratch_bytes(const ConvGeom& g) {
@@ -833,6 +834,38 @@ int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* d
     hipLaunchKernelGGL(wino_filtergrad_kernel, dim3(grid_for((int64_t)g.Co * g.Ci, 4096), 4), dim3(256), 0, st, dU, dwp, g.Co, g.Ci);
     ACL_CHECK_LAUNCH("wino_filtergrad_kernel(up5)");
     return ACLGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the 4x4 stride-2 reflect-pad-1 layers (ContentEncoder / StyleEncoder downsampling, MsImageDis layers 1..3: networks.py:41,
+// 216-221, 236-241) as four parity phases of the fused F(4x4,3x3) kernel (conv_wino_fused.hip: wino_fused_s2k4_*).  Forward in one launch
+// (K loop over phase x Cin, statistics of the following InstanceNorm from the epilogue), interior of the input gradient in one launch (four
+// grid phases writing the parity views of dx); the mirrored halo ring keeps the direct kernel's small launch.  ACLGAN_NOWINOS2=1 keeps the
+// direct kernels; the per-shape decision is wino_fused_s2k4_ok's cost model (aclgan_tuning("wino_fused", 2) takes every eligible shape).
+// ------------------------------------------------------------------------------------------
+bool conv_s2k4_wino_ok(const ConvGeom& g, int which) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ACLGAN_NOWINOS2"); off = (e && atoi(e)) ? 1 : 0; }
+    if (off || !wino_enabled() || g.k != 4 || g.s != 2 || g.p != 1 || g.up != 0) return false;
+    if (which == 1 && deterministic()) return false;      // (the ordered ring fold of that mode is wired for the 3x3 layers only)
+    return wino_fused_s2k4_ok(g.B, g.Hi, g.Wi, g.Ci, g.Co, which ? ACLGAN_ACT_NONE : g.act, which);
+}
+size_t conv_s2k4_wino_scratch_bytes(const ConvGeom& g) {
+    return (conv_s2k4_wino_ok(g, 0) || conv_s2k4_wino_ok(g, 1)) ? align256(wino_fused_s2k4_u_bytes(g.Ci, g.Co)) + 256 : 0;
+}
+int conv_fwd_s2k4_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats) {
+    if (!conv_s2k4_wino_ok(g, 0) || !scratch) return ACLGAN_EUNSUPPORTED;
+    bool fresh = true;
+    float* Uf = cached_u((float*)scratch, w, uvar(0, U_FRAG), wino_fused_s2k4_u_bytes(g.Ci, g.Co), &fresh);
+    if (fresh) { const int rcf = wino_fused_filter_s2k4(w, Uf, g.Co, g.Ci, 0, st); if (rcf) return rcf; }
+    return wino_fused_s2k4_fwd(g.B, g.Hi, g.Wi, g.Ci, g.Co, x, Uf, bias, y, g.act, (float2*)stats, st);
+}
+int conv_dgrad_s2k4_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st) {
+    if (!conv_s2k4_wino_ok(g, 1) || !scratch) return ACLGAN_EUNSUPPORTED;
+    bool fresh = true;
+    float* Uf = cached_u((float*)scratch, w, uvar(1, U_FRAG), wino_fused_s2k4_u_bytes(g.Ci, g.Co), &fresh);
+    if (fresh) { const int rcf = wino_fused_filter_s2k4(w, Uf, g.Co, g.Ci, 1, st); if (rcf) return rcf; }
+    return wino_fused_s2k4_dgrad(g.B, g.Hi, g.Wi, g.Ci, g.Co, dy, Uf, dx, accumulate, st);
 }
 
 }  // namespace aclgan

@@ -53,7 +53,7 @@ constexpr int M_BYTES = 36 * 32 * 32 * 4;        // epilogue exchange buffer (on
 struct WfP {
     const float* x; const float* Uf; const float* bias; float* y; float2* stats;
     int B, Cin, Cout;                                  // Cin: input channels of ONE K phase
-    int IH, IW, ivs, ivy0, ivx0, IHS, IWS, off, reflect;      // input view (logical extent IH x IW), patch offset, padding mode
+    int IH, IW, ivs, ivy0, ivx0, IHS, IWS, off, reflect;      // input view (logical extent IH x IW), patch offset, padding mode (0 zero, 1 reflect, 2 edge)
     int nkph;                                          // K phases: the K loop runs over nkph x Cin channels (input gradient of the sub-pixel layers:
     int kph_xoff[4];                                   //   the four phase views of dy, byte offset of view ph relative to view 0) ...
     int uphase;                                        //   ... with U of K phase / grid phase ph starting uphase bytes after the previous one
@@ -94,12 +94,24 @@ __device__ __forceinline__ void g6f(const float (&g)[3], float (&u)[6]) {
 //   frequency (i, jf): wave g = (i / 3) * 2 + jf / 3, fi = (i % 3) * 3 + jf % 3
 // blockIdx.y = filter of a batch (w + y * wstr -> Uf + y * ustr floats): the merged phase filters of a sub-pixel layer, or -- round 5 -- all
 // equally shaped ResBlock filters of an encoder / decoder (wstr = their distance in the flat parameter buffer)
+// mode 0: a 3x3 filter w[Co][3][3][Ci] (flip: the flipped, transposed filter of the input gradient).
+// mode 1 / 2 (round 6): the polyphase 3x3 embeddings of a 4x4 STRIDE-2 filter w[Co][4][4][Ci] (networks.py:41, 216-221, 236-241), blockIdx.y = phase
+// (py, px).  A 4x4 stride-2 pad-1 convolution is the sum over the four input parity phases of a 2-tap-per-axis stride-1 convolution of the
+// decimated input; each 2-tap filter sits in a 3-tap window (one tap structurally zero) so that the F(4x4,3x3) kernel runs it: 36 multiplies
+// per 16 outputs and phase instead of 64.  Tap t of the window [u - 1, u, u + 1] reads filter row s2k4_tap(...) (or nothing):
+//   mode 1, forward   (rows = cout, k = cin): even input rows: y[u] += w1 E[u] + w3 E[u+1];  odd rows: y[u] += w0 O[u-1] + w2 O[u]
+//   mode 2, input gradient (rows = cin, k = cout; phase = parity of the dx row): dx[2m] = w3 dy[m-1] + w1 dy[m];  dx[2m+1] = w2 dy[m] + w0 dy[m+1]
+__device__ __forceinline__ int s2k4_tap(int mode, int par, int t) {
+    if (mode == 1) return par == 0 ? (t == 0 ? -1 : (t == 1 ? 1 : 3)) : (t == 0 ? 0 : (t == 1 ? 2 : -1));
+    return par == 0 ? (t == 0 ? 3 : (t == 1 ? 1 : -1)) : (t == 0 ? -1 : (t == 1 ? 2 : 0));
+}
 __global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __restrict__ w, float* __restrict__ Uf, int Co, int Ci, int flip,
-                                                               int64_t wstr, int64_t ustr) {
+                                                               int64_t wstr, int64_t ustr, int mode) {
     const int R = flip ? Ci : Co, K = flip ? Co : Ci, KQ = K >> 2;
     const int64_t n = (int64_t)R * K;
     w += (size_t)blockIdx.y * wstr;
     Uf += (size_t)blockIdx.y * ustr;
+    const int py = (int)(blockIdx.y >> 1) & 1, px = (int)blockIdx.y & 1;      // (modes 1, 2)
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
         // consecutive threads -> consecutive rows of one k (the 36 stores of a wave then fill 128-byte runs of the fragment layout)
         const int row = (int)(idx % R), kk = (int)(idx / R);
@@ -110,8 +122,13 @@ __global__ void __launch_bounds__(256) wino_filter_frag_kernel(const float* __re
             float c[3];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
-                c[ky] = w[((size_t)(co * 3 + sy) * 3 + sx) * Ci + ci];
+                if (mode == 0) {
+                    const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                    c[ky] = w[((size_t)(co * 3 + sy) * 3 + sx) * Ci + ci];
+                } else {
+                    const int sy = s2k4_tap(mode, py, ky), sx = s2k4_tap(mode, px, kx);
+                    c[ky] = (sy >= 0 && sx >= 0) ? w[((size_t)(co * 4 + sy) * 4 + sx) * Ci + ci] : 0.f;
+                }
             }
             float o[6];
             g6f(c, o);
@@ -354,7 +371,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const int pix = s / JN, j = s - pix * JN;
             const int r = pix / PC, c = pix - r * PC;
             int iy = 4 * ty0 + p.off + r, ix = 4 * tx0 + p.off + c;
-            if (p.reflect) { iy = reflf(iy, p.IH); ix = reflf(ix, p.IW); }
+            if (p.reflect == 1) { iy = reflf(iy, p.IH); ix = reflf(ix, p.IW); }
+            else if (p.reflect == 2) { iy = min(max(iy, 0), p.IH - 1); ix = min(max(ix, 0), p.IW - 1); }      // edge replication (parity phases of a stride-2 layer)
             if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
                 go[i] = (unsigned int)((((size_t)b * p.IHS + p.ivy0 + p.ivs * iy) * p.IWS + p.ivx0 + p.ivs * ix) * p.Cin * 4 + j * 16);
             lub[i] = (2 * j * QS + r * RS + (c & 3) * 9 + (c >> 2)) * 8;
@@ -515,7 +533,7 @@ size_t wino_fused_u_bytes(int Cin_, int Cout_) { return (size_t)36 * Cin_ * Cout
 int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipStream_t st, int nph) {
     const int64_t n = (int64_t)Co * Ci;
     hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096), nph), dim3(256), 0, st, w, Uf, Co, Ci, flip,
-                       (int64_t)Co * 9 * Ci, (int64_t)36 * n);
+                       (int64_t)Co * 9 * Ci, (int64_t)36 * n, 0);
     ACL_CHECK_LAUNCH("wino_filter_frag_kernel");
     return ACLGAN_OK;
 }
@@ -523,7 +541,7 @@ int wino_fused_filter(const float* w, float* Uf, int Co, int Ci, int flip, hipSt
 int wino_fused_filter_batch(const float* w0, int64_t w_stride, float* Uf0, int64_t u_stride, int count, int Co, int Ci, int flip, hipStream_t st) {
     const int64_t n = (int64_t)Co * Ci;
     hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 1024), count), dim3(256), 0, st, w0, Uf0, Co, Ci, flip,
-                       w_stride, u_stride);
+                       w_stride, u_stride, 0);
     ACL_CHECK_LAUNCH("wino_filter_frag_kernel(batch)");
     return ACLGAN_OK;
 }
@@ -596,6 +614,76 @@ int wino_fused_up5_dgrad(int B, int Hi, int Wi, int Cin_, int Cout_, const float
     p.OH = Hi; p.OW = Wi; p.ovs = 1; p.OHS = Hi; p.OWS = Wi;
     p.act = ACLGAN_ACT_NONE; p.accumulate = accumulate;
     return wino_fused_go(p, 1, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the 4x4 STRIDE-2 reflect-pad-1 layers (content / style encoder downsampling, discriminator layers 1..3: networks.py:41, 216-221,
+// 236-241) through the same kernel.  y[oy] = sum_k w[k] xpad[2 oy + k] splits by the parity of the input row into two 2-tap stride-1
+// convolutions of the decimated input (polyphase); a 2-tap filter embedded in the 3-tap window of F(4x4,3x3) costs 36 multiplies per 16
+// outputs and phase, 4 phases: 9 per output and input channel against 16 for the direct kernel (1.78x fewer MACs).
+//   forward: ONE K loop over the four parity views of x (stride-2 views, K phases) x Cin.  ReflectionPad2d(1) of the full-resolution
+//            map is EDGE replication in every parity view (row -1 -> row 1 = odd[0], row H -> row H - 2 = even[H/2 - 1]); the replicated
+//            sample a view does not need meets its structurally zero tap (s2k4_tap).
+//   input gradient (interior of the padded grid): dx of parity phase (py, px) is a 3-window correlation of dy (zero padding) with the
+//            embedded taps: four grid phases writing stride-2 views of dx, K = Cout.  The mirrored halo ring keeps its small direct launch.
+// Uf: the four embedded phase filters in fragment order, back to back (wino_fused_filter_s2k4).
+// ------------------------------------------------------------------------------------------
+int wino_fused_filter_s2k4(const float* w, float* Uf, int Co, int Ci, int dgrad, hipStream_t st) {
+    const int64_t n = (int64_t)Co * Ci;
+    hipLaunchKernelGGL(wino_filter_frag_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 4096), 4), dim3(256), 0, st, w, Uf, Co, Ci, dgrad ? 1 : 0,
+                       (int64_t)0, (int64_t)36 * n, dgrad ? 2 : 1);
+    ACL_CHECK_LAUNCH("wino_filter_frag_kernel(s2k4)");
+    return ACLGAN_OK;
+}
+// Cost model (microseconds; the fused kernel as in wino_fused_ok, the direct implicit-GEMM kernels at the rates of the round-5 trace:
+// 115 - 145 TFLOP/s on full grids, far less once split-K has to fill the chip) -- mode 1 asks it, mode 2 takes every eligible shape.
+bool wino_fused_s2k4_ok(int B, int Hi, int Wi, int Ci, int Co, int act, int dgrad) {
+    const int m = tl_wino_force > 0 ? 2 : (wino_fused_mode() & 15);
+    if (m == 0) return false;
+    const int Cin_ = dgrad ? Co : Ci, Cout_ = dgrad ? Ci : Co;      // the kernel's K-side / output-side channels
+    const bool shape = act != ACLGAN_ACT_TANH && Hi % 2 == 0 && Wi % 2 == 0 && Hi >= 8 && Wi >= 8 && Cin_ % (2 * KC) == 0 && Cout_ % NBC == 0 &&
+                       (long long)4 * 36 * Ci * Co * 4 < 0x7fffffe0ll && (long long)B * Hi * Wi * std::max(Ci, Co) * 4 < 0x7fffffe0ll;
+    if (!shape || m == 2) return shape;
+    const int OH = Hi / 2, OW = Wi / 2, TY = cdiv(OH, 4), TX = cdiv(OW, 4);
+    const int gph = dgrad ? 4 : 1, kph = dgrad ? 1 : 4;
+    const double nwg = (double)B * cdiv(TY, TBY) * cdiv(TX, TBX) * (Cout_ / NBC) * gph;
+    const double t_fused = (10.0 + 83.0 * (double)Cin_ * kph / 256.0) * std::ceil(nwg / 256.0);
+    const double flop = 2.0 * B * OH * OW * 16.0 * Ci * Co;
+    const double nblk = (double)cdiv(B * OH * OW, 128) * cdiv(dgrad ? Ci : Co, 128) * (dgrad ? 4 : 1);
+    const double t_direct = 8.0 + flop / (nblk >= 256 ? 120e6 : 60e6 + 60e6 * nblk / 256.0);
+    return t_fused <= 0.95 * t_direct;
+}
+size_t wino_fused_s2k4_u_bytes(int Ci, int Co) { return (size_t)144 * Ci * Co * sizeof(float); }
+
+// y[B][Hi/2][Wi/2][Co] = act(conv4x4 stride 2, reflect pad 1 (x[B][Hi][Wi][Ci]) + bias); stats (optional): (mean, M2) of the 4x4 output tiles
+int wino_fused_s2k4_fwd(int B, int Hi, int Wi, int Ci, int Co, const float* x, const float* Uf, const float* bias, float* y, int act, float2* stats,
+                        hipStream_t st) {
+    if (!wino_fused_s2k4_ok(B, Hi, Wi, Ci, Co, act, 0)) return ACLGAN_EUNSUPPORTED;
+    const int OH = Hi / 2, OW = Wi / 2;
+    if (stats && (OH % 4 != 0 || OW % 4 != 0)) return ACLGAN_EUNSUPPORTED;
+    WfP p;
+    p.x = x; p.Uf = Uf; p.bias = bias; p.y = y; p.stats = stats;
+    p.B = B; p.Cin = Ci; p.Cout = Co;
+    p.IH = OH; p.IW = OW; p.ivs = 2; p.ivy0 = 0; p.ivx0 = 0; p.IHS = Hi; p.IWS = Wi; p.off = -1; p.reflect = 2;
+    p.nkph = 4;
+    for (int i = 0; i < 4; ++i) { p.kph_xoff[i] = ((i >> 1) * Wi + (i & 1)) * Ci * 4; p.ovy0[i] = 0; p.ovx0[i] = 0; }
+    p.OH = OH; p.OW = OW; p.ovs = 1; p.OHS = OH; p.OWS = OW;
+    p.act = act; p.accumulate = 0;
+    return wino_fused_go(p, 1, st);
+}
+// dx[B][Hi][Wi][Ci] (+)= the interior of the padded-grid gradient of the same layer from dy[B][Hi/2][Wi/2][Co]
+int wino_fused_s2k4_dgrad(int B, int Hi, int Wi, int Ci, int Co, const float* dy, const float* Uf, float* dx, int accumulate, hipStream_t st) {
+    if (!wino_fused_s2k4_ok(B, Hi, Wi, Ci, Co, ACLGAN_ACT_NONE, 1)) return ACLGAN_EUNSUPPORTED;
+    const int OH = Hi / 2, OW = Wi / 2;
+    WfP p;
+    p.x = dy; p.Uf = Uf; p.bias = nullptr; p.y = dx; p.stats = nullptr;
+    p.B = B; p.Cin = Co; p.Cout = Ci;
+    p.IH = OH; p.IW = OW; p.ivs = 1; p.ivy0 = 0; p.ivx0 = 0; p.IHS = OH; p.IWS = OW; p.off = -1; p.reflect = 0;
+    p.nkph = 1;
+    for (int i = 0; i < 4; ++i) { p.kph_xoff[i] = 0; p.ovy0[i] = i >> 1; p.ovx0[i] = i & 1; }
+    p.OH = OH; p.OW = OW; p.ovs = 2; p.OHS = Hi; p.OWS = Wi;
+    p.act = ACLGAN_ACT_NONE; p.accumulate = accumulate;
+    return wino_fused_go(p, 4, st);
 }
 
 }  // namespace aclgan

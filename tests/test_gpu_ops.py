@@ -156,6 +156,54 @@ def test_winograd_fused_kernel(L, case):
     assert rel_err(out[2][0], out[0][0]) < 5e-5 and rel_err(out[2][1], out[0][1]) < 5e-5
 
 
+S2K4_CASES = [
+    (2, 16, 16, 64, 128, 4, 2, 1, 0, "none"),     # CE1 / SE1 / D layer 1 shape (reduced map)
+    (1, 16, 16, 128, 256, 4, 2, 1, 0, "relu"),    # CE2 / SE2, activation in the epilogue
+    (2, 8, 8, 256, 512, 4, 2, 1, 0, "lrelu"),     # D layer 3: one (half-empty) tile block per image
+    (3, 12, 20, 64, 64, 4, 2, 1, 0, "lrelu"),     # 6 x 10 outputs: ragged last tiles in both directions, B = 3
+    (1, 34, 18, 32, 64, 4, 2, 1, 0, "none"),      # 17 x 9 outputs (odd), Cin 32
+    (2, 64, 64, 64, 128, 4, 2, 1, 0, "none"),     # several tile blocks per image (2 x 1 blocks of 8 x 4 tiles)
+    (1, 72, 40, 128, 64, 4, 2, 1, 0, "none"),     # 36 x 20 outputs: 2 x 3 tile blocks, the last ones partly empty; Cin > Cout
+]
+
+
+@pytest.mark.parametrize("case", S2K4_CASES)
+def test_stride2_layers_through_the_fused_winograd_kernel(L, case):
+    """Round 6 (csrc/conv_wino_fused.hip, wino_fused_s2k4_*): ReflectionPad2d(1) + Conv2d(4x4, stride 2) (networks.py:41, 216-221, 236-241) as the
+    four input-parity phases of the fused F(4x4,3x3) kernel -- forward (K loop over phase x Cin, edge replication in the parity views) and the
+    interior of the input gradient (four grid phases writing the parity views of dx; the mirrored halo keeps its direct launch).  FORCED
+    (tuning mode 2) on small and ragged maps, against the oracle and against the direct kernels (mode 0), accumulate mode included."""
+    from gpu_util import conv_desc, gpu_conv_fwd, gpu_conv_dgrad, nhwc, nchw, ohwi, rel_err
+    B, Hi, Wi, Ci, Co, k, s, p, up, act = case
+    x, w, b = _case_tensors(case, 11)
+    x.requires_grad_(True)
+    ref = O.conv_block(x, w, b, s, p, act, upsample=False)
+    y_lin = O.conv_block(x, w, b, s, p, "none", upsample=False)
+    dy = torch.randn(y_lin.shape, generator=torch.Generator().manual_seed(5))
+    y_lin.backward(dy)
+    d = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, act)
+    dn = conv_desc(L, B, Hi, Wi, Ci, Co, k, s, p, up, "none")
+    xg, wg, bg, dyg = nhwc(x.detach()).cuda(), ohwi(w).cuda(), b.cuda(), nhwc(dy).cuda()
+    base = torch.randn(B, Hi, Wi, Ci, generator=torch.Generator().manual_seed(6))
+    out = {}
+    old = L.lib.aclgan_set_tuning(b"wino_fused", 0)
+    try:
+        for v in (0, 2):
+            L.lib.aclgan_set_tuning(b"wino_fused", v)
+            y = gpu_conv_fwd(L, d, xg, wg, bg)
+            out[v] = (y, gpu_conv_dgrad(L, dn, dyg, wg), gpu_conv_dgrad(L, dn, dyg, wg, accumulate_into=base.clone().cuda()), gpu_conv_fwd(L, d, xg, wg, bg))
+    finally:
+        L.lib.aclgan_set_tuning(b"wino_fused", old)
+    for v in (0, 2):
+        assert rel_err(nchw(out[v][0]), ref) < TOL
+        assert rel_err(nchw(out[v][1]), x.grad) < TOL
+        assert rel_err(nchw(out[v][2]).cpu() - nchw(base), x.grad) < 5 * TOL
+        assert torch.equal(out[v][0], out[v][3])          # the forward is reproducible bit for bit on either path
+    # different arithmetic (so the forced mode did take the other kernel), same result to the transforms' rounding
+    assert not torch.equal(out[2][0], out[0][0]) and (L.lib.aclgan_get_deterministic() or not torch.equal(out[2][1], out[0][1]))
+    assert rel_err(out[2][0], out[0][0]) < 5e-5 and rel_err(out[2][1], out[0][1]) < 5e-5
+
+
 WGRAD_FUSED_CASES = [(1, 16, 16, 64, 64), (2, 16, 32, 64, 64), (1, 8, 32, 64, 128), (3, 20, 48, 64, 64), (7, 12, 16, 128, 64), (2, 64, 64, 256, 256), (5, 32, 32, 128, 128)]
 
 
@@ -437,7 +485,9 @@ BLOCK_CASES = [
     (3, 8, 8, 64, 128, 3, "adain", "relu", False, True),      # decoder ResBlock (AdaIN), Cin != Cout
     (1, 64, 64, 64, 64, 3, "ln", "relu", False, True),        # LN over the tile partials (256 tiles x 64 channels)
     (2, 10, 12, 64, 64, 3, "in", "relu", False, False),       # H % 4 != 0: direct kernel, separate statistics pass
-    (2, 16, 16, 64, 128, 4, "in", "relu", False, False),      # strided encoder conv: separate statistics pass
+    (2, 16, 16, 64, 128, 4, "in", "relu", False, "s2"),       # strided encoder conv: statistics from the epilogue where the fused kernel runs it
+    (1, 24, 40, 128, 256, 4, "in", "relu", False, "s2"),      # ... non-square, 12 x 20 outputs (whole 4x4 tiles)
+    (2, 12, 20, 64, 128, 4, "in", "relu", False, False),      # ... 6 x 10 outputs: not whole tiles -> separate statistics pass
 ]
 
 
@@ -483,6 +533,8 @@ def test_conv_block_fwd(L, case, wino_mode):
     L.check(L.lib.aclgan_conv2d_block_fwd(C.byref(d), L.NORM[kind], L.ACT[act], L.ptr(xg), L.ptr(wg), L.ptr(bg), L.ptr(nwg), L.ptr(nbg),
                                           Co if kind == "adain" else 0, L.ptr(resg), L.ptr(yc), L.ptr(y), L.ptr(mean), L.ptr(rstd),
                                           L.ptr(scratch), C.byref(fused), L.stream_ptr()), "conv2d_block_fwd")
+    if expect_fused == "s2":      # (round 6) the stride-2 layers take the fused kernel in forced mode (2); the default asks the cost model
+        expect_fused = wino_mode == 2
     assert fused.value == int(expect_fused)
     assert rel_err(nchw(yc), yc_ref) < TOL
     assert rel_err(nchw(y), y_ref) < TOL
