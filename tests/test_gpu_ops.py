@@ -200,7 +200,8 @@ def test_stride2_layers_through_the_fused_winograd_kernel(L, case):
         assert rel_err(nchw(out[v][2]).cpu() - nchw(base), x.grad) < 5 * TOL
         assert torch.equal(out[v][0], out[v][3])          # the forward is reproducible bit for bit on either path
     # different arithmetic (so the forced mode did take the other kernel), same result to the transforms' rounding
-    assert not torch.equal(out[2][0], out[0][0]) and (L.lib.aclgan_get_deterministic() or not torch.equal(out[2][1], out[0][1]))
+    # (the input gradient's output channels are the layer's INPUT channels: Cin 32 stays on the direct kernel)
+    assert not torch.equal(out[2][0], out[0][0]) and (L.lib.aclgan_get_deterministic() or Ci % 64 != 0 or not torch.equal(out[2][1], out[0][1]))
     assert rel_err(out[2][0], out[0][0]) < 5e-5 and rel_err(out[2][1], out[0][1]) < 5e-5
 
 
