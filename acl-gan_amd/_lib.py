@@ -81,6 +81,9 @@ SIGNATURES = {
     "aclgan_ctx_create": (ci, [C.POINTER(Arch), C.POINTER(vp)]),
     "aclgan_ctx_destroy": (None, [vp]),
     "aclgan_ctx_enable_capture": (ci, [vp]),
+    "aclgan_debug_capture_masks": (ci, [vp, vp, sz]),
+    "aclgan_debug_mask_count": (ci, [vp]),
+    "aclgan_debug_mask_info": (ci, [vp, ci, C.POINTER(ci), C.POINTER(C.c_longlong), C.POINTER(ci)]),
     "aclgan_group_numel": (i64, [vp, ci]),
     "aclgan_tensor_count": (ci, [vp, ci]),
     "aclgan_tensor_info": (ci, [vp, ci, ci, C.c_char_p, ci, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci)]),
@@ -117,6 +120,7 @@ SIGNATURES = {
     "aclgan_conv2d_fwd16s": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp]),
     "aclgan_set_tuning": (ci, [C.c_char_p, ci]),
     "aclgan_tuning": (ci, [C.c_char_p, ci, C.POINTER(ci)]),
+    "aclgan_tuning_get": (ci, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "aclgan_check_workspace": (ci, [vp, ci, ci, ci]),
     "aclgan_conv2d_fwd16s_stats_chunk": (ci, [C.POINTER(ConvDesc)]),
     "aclgan_conv2d_fwd16s_stats": (ci, [C.POINTER(ConvDesc), ci, vp, vp, vp, vp, ci, vp, vp]),

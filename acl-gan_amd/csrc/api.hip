@@ -28,8 +28,10 @@ int hip_fail(hipError_t e, const char* what) {
 static std::atomic<int> g_lanes{-1}, g_u_batch{-1}, g_norm_mask{-1};
 static std::atomic<long long> g_tuning_epoch{0};
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-int lanes_setting() { int v = g_lanes.load(); if (v < 0) { v = std::max(1, std::min(4, env_int("ACLGAN_LANES", 3))); g_lanes.store(v); } return v; }
-int set_lanes(int v) { const int old = lanes_setting(); g_lanes.store(std::max(1, std::min(4, v))); return old; }
+// (1 .. 3: the updates assign work to lanes 0 .. 2 only; a value of 4 used to be accepted, ran the 3-lane plan and still created a 4th pooled
+//  stream, which shifts HIP's stream -> hardware-queue placement -- clamped since round 6)
+int lanes_setting() { int v = g_lanes.load(); if (v < 0) { v = std::max(1, std::min(3, env_int("ACLGAN_LANES", 3))); g_lanes.store(v); } return v; }
+int set_lanes(int v) { const int old = lanes_setting(); g_lanes.store(std::max(1, std::min(3, v))); return old; }
 int u_batch_setting() { int v = g_u_batch.load(); if (v < 0) { v = env_int("ACLGAN_U_BATCH", 1) ? 1 : 0; g_u_batch.store(v); } return v; }
 int set_u_batch(int v) { const int old = u_batch_setting(); g_u_batch.store(v ? 1 : 0); return old; }
 int norm_mask_setting() { int v = g_norm_mask.load(); if (v < 0) { v = env_int("ACLGAN_NORM_MASK", 1) ? 1 : 0; g_norm_mask.store(v); } return v; }
@@ -281,6 +283,22 @@ int aclgan_tuning(const char* key, int value, int* previous) {
     else { set_error("aclgan_tuning: unknown key '%s'", key); return ACLGAN_EINVAL; }
     bump_tuning_epoch();
     if (previous) *previous = old;
+    return ACLGAN_OK;
+}
+// read a switch without touching it (no epoch bump, no window in which another thread sees a different value); ACLGAN_EINVAL for an unknown key.
+// key "epoch": the number of aclgan_tuning calls so far (what cached, switch-dependent results are keyed by: workspace sizes)
+int aclgan_tuning_get(const char* key, long long* value) {
+    ACL_REQUIRE(key && value, "aclgan_tuning_get: null argument");
+    if (!strcmp(key, "epoch")) { *value = tuning_epoch(); return ACLGAN_OK; }
+    int old = 0;
+    if (!strcmp(key, "wino_fused")) old = wino_fused_mode();
+    else if (!strcmp(key, "wino_wgrad_fused")) old = wino_wgrad_fused_mode();
+    else if (!strcmp(key, "lanes")) old = lanes_setting();
+    else if (!strcmp(key, "u_batch")) old = u_batch_setting();
+    else if (!strcmp(key, "norm_mask")) old = norm_mask_setting();
+    else if (!strcmp(key, "fault_at")) old = fault_at_setting();
+    else { set_error("aclgan_tuning_get: no getter for key '%s'", key); return ACLGAN_EINVAL; }      // (the 16-bit kernel-variant switches are write-only test knobs)
+    *value = old;
     return ACLGAN_OK;
 }
 // (round 3 form, kept: the previous value in the return value, -1 for an unknown key)

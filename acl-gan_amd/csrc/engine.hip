@@ -215,6 +215,11 @@ struct aclgan_ctx {
     double alg_bytes = 0.0;
     void count(double bytes) { alg_bytes += bytes; }
     size_t keep_total = 0;      // bytes of Winograd input transforms kept for the weight gradients of this update (conv_block)
+    // diagnostics (aclgan_debug_capture_masks): the ReLU / LeakyReLU masks of every Conv2dBlock an update back-propagates through, one byte per
+    // element, appended to a caller-owned device buffer in the order the forward builds them (tests/test_gpu_maskfrozen.py)
+    struct MaskEnt { int B, H, W, C, act; long long off; };
+    unsigned char* mask_dst = nullptr; size_t mask_cap = 0, mask_top = 0;
+    std::vector<MaskEnt> mask_log;
     // Winograd filter transforms of this update, by (filter tensor, variant): computed by the first layer call that needs one, reused by
     // the later calls of the same network (common.h: WinoUCache); the buffers live in the arena until the update ends
     struct UEnt { float* u; bool filled; int layout; int lane, ck; };
@@ -237,7 +242,8 @@ struct aclgan_ctx {
         }
         if (e.layout != layout) return nullptr;
         *fresh = false;
-        if (bytes && c->nlanes > 1 && e.lane != c->cur_lane) (void)c->wait_ck(c->cur_lane, e.lane, e.ck);
+        // (a failed cross-lane wait must not hand out a transform another lane may still be writing: the caller recomputes into its own scratch)
+        if (bytes && c->nlanes > 1 && e.lane != c->cur_lane && c->wait_ck(c->cur_lane, e.lane, e.ck) != ACLGAN_OK) return nullptr;
         return e.u;
     }
     // make sure the arena holds a slot for the transform of (w, variant); call where an allocation may persist until the update ends
@@ -780,6 +786,14 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     }
     c.top = mark;
     *out_p = out;
+    if (c.mask_dst && !c.dry && want_grad && (act == ACLGAN_ACT_RELU || act == ACLGAN_ACT_LRELU)) {
+        // diagnostics: the mask this block's backward will apply = the sign of its activated output (out > 0 <=> pre-activation > 0)
+        const size_t n = (size_t)out->numel();
+        if (c.mask_top + n > c.mask_cap) { set_error("aclgan_debug_capture_masks: buffer too small (%zu bytes)", c.mask_cap); return ACLGAN_ENOMEM; }
+        RUN(positive_mask(out->d, out->dt, c.mask_dst + c.mask_top, (int64_t)n, c.st));
+        c.mask_log.push_back(aclgan_ctx::MaskEnt{out->B, out->H, out->W, out->C, act, (long long)c.mask_top});
+        c.mask_top += n;
+    }
     c.wrote(out); c.wrote(co);
     if (!want_grad) return ACLGAN_OK;
     aclgan_ctx* cp = &c;
@@ -1563,6 +1577,21 @@ int aclgan_ctx_enable_capture(aclgan_ctx* ctx) {
     return ctx->make_private_side();
 }
 
+int aclgan_debug_capture_masks(aclgan_ctx* ctx, unsigned char* dst, size_t cap_bytes) {
+    ACL_REQUIRE(ctx, "null ctx");
+    ctx->mask_dst = dst; ctx->mask_cap = dst ? cap_bytes : 0; ctx->mask_top = 0; ctx->mask_log.clear();
+    return ACLGAN_OK;
+}
+int aclgan_debug_mask_count(const aclgan_ctx* ctx) { return ctx ? (int)ctx->mask_log.size() : 0; }
+int aclgan_debug_mask_info(const aclgan_ctx* ctx, int index, int* dims4, long long* offset, int* act) {
+    ACL_REQUIRE(ctx && index >= 0 && index < (int)ctx->mask_log.size(), "mask index out of range");
+    const aclgan_ctx::MaskEnt& e = ctx->mask_log[index];
+    if (dims4) { dims4[0] = e.B; dims4[1] = e.H; dims4[2] = e.W; dims4[3] = e.C; }
+    if (offset) *offset = e.off;
+    if (act) *act = e.act;
+    return ACLGAN_OK;
+}
+
 int aclgan_set_compute_dtype(aclgan_ctx* ctx, int dtype) {
     ACL_REQUIRE(ctx && dtype >= ACLGAN_DTYPE_FP32 && dtype <= ACLGAN_DTYPE_FP16, "bad ctx / dtype %d", dtype);
     ctx->dtype = dtype;
@@ -1621,6 +1650,7 @@ static int update_need_bytes(aclgan_ctx& c, int which, int B, int H, int W, size
     c.dry = false; c.trained = -1;
     *out = c.peak + c.peak2 + 512;
     c.reset_step();
+    c.peak = 0; c.peak2 = 0;      // a dry run leaves no allocator state behind (a stale side-stack mark made later forward-only calls fail spuriously)
     return rc;
 }
 int aclgan_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t* out) {
@@ -1668,6 +1698,7 @@ int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int 
     c.bucket_fn = keep;
     c.dry = false; c.trained = -1;
     c.reset_step();
+    c.peak = 0; c.peak2 = 0;
     if (rc) return rc;
     *out = c.alg_bytes + (4.0 + 28.0) * (double)c.groups[which].numel;    // + zero_grad + Adam (p, g, m, v read; p, m, v written)
     return ACLGAN_OK;
@@ -1683,7 +1714,7 @@ int aclgan_forward_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t*
     size_t best = 0;
     for (int which = 0; which < 3; ++which) {
         c.reset_step();
-        c.dry = true; c.peak = 0; c.trained = -1;
+        c.dry = true; c.peak = 0; c.peak2 = 0; c.trained = -1;
         Act *x = nullptr, *o = nullptr, *s = nullptr;
         std::vector<Act*> outs;
         int rc = ACLGAN_OK;
@@ -1793,6 +1824,7 @@ int aclgan_bucket_schedule(aclgan_ctx* ctx, int group, int B, int H, int W, int 
                               : dis_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr);
     c.dry = false; c.fire_dry = false; c.trained = -1;
     c.reset_step();
+    c.peak = 0; c.peak2 = 0;
     if (rc) return rc;
     *count = (int)c.bucket_order.size();
     for (int i = 0; i < *count && i < cap && order; ++i) order[i] = c.bucket_order[i];
@@ -1818,7 +1850,8 @@ static int fwd_begin(aclgan_ctx* ctx, void* stream) {
     ACL_REQUIRE(ctx && ctx->ws, "bind a workspace first");
     ACL_REQUIRE(ctx->groups[0].param && ctx->groups[1].param, "bind parameters first");
     ctx->reset_step();
-    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0; ctx->trained = -1;
+    // (peak2: the side stack's high-water mark of whatever ran before -- an update, a dry run -- is not this call's: a forward-only arena has no side stack)
+    ctx->st = (hipStream_t)stream; ctx->dry = false; ctx->peak = 0; ctx->peak2 = 0; ctx->trained = -1;
     return ACLGAN_OK;
 }
 

@@ -62,6 +62,23 @@ int act_bwd_inplace(int act, const void* y, void* dy, int64_t n, hipStream_t st,
     return ACLGAN_OK;
 }
 
+// ---- diagnostics: dst[i] = (y[i] > 0) as one byte per element (aclgan_debug_capture_masks: the activation masks an update ran with) ----
+__global__ void positive_mask_kernel(const void* __restrict__ y, int yst, unsigned char* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const st_f32x4 v = st_ld4(y, i, yst);
+        uchar4 m;
+        m.x = v[0] > 0.f; m.y = v[1] > 0.f; m.z = v[2] > 0.f; m.w = v[3] > 0.f;
+        reinterpret_cast<uchar4*>(dst)[i] = m;
+    }
+}
+int positive_mask(const void* y, int yst, unsigned char* dst, int64_t n, hipStream_t st) {
+    ACL_REQUIRE(n % 4 == 0, "positive_mask: %lld elements (must be a multiple of 4)", (long long)n);
+    if (n == 0) return ACLGAN_OK;
+    hipLaunchKernelGGL(positive_mask_kernel, dim3((int)std::min<int64_t>(cdiv64(n / 4, 256), 8192)), dim3(256), 0, st, y, yst, dst, n / 4);
+    ACL_CHECK_LAUNCH("positive_mask_kernel");
+    return ACLGAN_OK;
+}
+
 // ---- storage conversion (fp32 <-> bf16 / fp16), four elements per thread ----
 __global__ void cast_storage_kernel(const void* __restrict__ src, int sst, void* __restrict__ dst, int dst_st, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) st_st4(dst, i, st_ld4(src, i, sst), dst_st);

@@ -380,7 +380,11 @@ class aclgan_Trainer:
         forward: inference must not inherit the training step's shape constraints or its arena size)."""
         key = (B, H, W)
         have = self._ws_shape
-        if have is not None and have[0] >= B and have[1:3] == (H, W) and (forward_only or have[3]):
+        # (an update's need depends on the library's tuning switches -- lanes, batched transforms, kernel choices: the cached size is
+        #  valid for one tuning epoch; after aclgan_tuning the next call sizes and binds again instead of failing with ACLGAN_ENOMEM)
+        ep = C.c_longlong()
+        L.check(L.lib.aclgan_tuning_get(b"epoch", C.byref(ep)), "tuning_get")
+        if have is not None and have[0] >= B and have[1:3] == (H, W) and (forward_only or (have[3] and have[4] == ep.value)):
             return
         need = C.c_size_t()
         if forward_only:
@@ -398,7 +402,7 @@ class aclgan_Trainer:
                 gc.collect(); torch.cuda.empty_cache()
                 self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         L.check(L.lib.aclgan_bind_workspace(self._ctx, L.ptr(self._ws), self._ws.numel()), "bind_workspace")
-        self._ws_shape = key + (not forward_only,)
+        self._ws_shape = key + (not forward_only, ep.value)
 
     def loss_scale_state(self):
         """fp16 only: {'scale', 'clean_updates', 'skipped_gen', 'skipped_dis'} (one device->host copy)."""

@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-floor", action="store_true", help="skip the 64x64 B=1 launch-bound probe (keeps kernel traces clean)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (the other single-GPU shapes of BASELINE.json, 5 steps each, after the timed region)")
-    ap.add_argument("--lanes", type=int, default=None, help="streams the independent branches of an update are spread over (default: the library's, ACLGAN_LANES or 2; 1 = one queue)")
+    ap.add_argument("--lanes", type=int, default=None, help="streams the independent branches of an update are spread over (1 .. 3; default: the library's, ACLGAN_LANES or 3; 1 = one queue)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -332,11 +332,10 @@ def main():
     if args.lanes is not None:
         L.check(L.lib.aclgan_tuning(b"lanes", args.lanes, None), "tuning lanes")
 
-    def tuning_value(key):      # (read a switch: set it to itself)
-        prev = C.c_int()
-        L.check(L.lib.aclgan_tuning(key, 0, C.byref(prev)), "tuning")
-        L.check(L.lib.aclgan_tuning(key, prev.value, None), "tuning")
-        return prev.value
+    def tuning_value(key):      # (read a switch; the getter changes nothing)
+        v = C.c_longlong()
+        L.check(L.lib.aclgan_tuning_get(key, C.byref(v)), "tuning_get")
+        return int(v.value)
 
     cfg["display_size"] = 1
     if os.environ.get("ACLGAN_BENCH_TEST_WIDTH"):      # test hook (tests/test_gpu_ddp.py): the control flow of N ranks sharing one GPU over gloo, with

@@ -157,6 +157,18 @@ void aclgan_ctx_destroy(aclgan_ctx* ctx);
  * every additional stream shifts HIP's stream -> hardware-queue placement (measured: 3 ms on the eager fp32 step). */
 int aclgan_ctx_enable_capture(aclgan_ctx* ctx);
 
+/* Diagnostics for the parity tests (round 6; tests/test_gpu_maskfrozen.py): record the ReLU / LeakyReLU masks the following updates run with.
+ * Every Conv2dBlock (networks.py:365-371) an update back-propagates through appends (output > 0) of its activated output -- exactly the
+ * mask its backward applies -- as one byte per element, NHWC, to `dst` (device memory, cap_bytes; NULL turns the recording off) in the
+ * order the forward builds the blocks; aclgan_debug_mask_count / _info enumerate them (dims4 = B, H, W, C; offset into dst; act = the
+ * ACLGAN_ACT_* code).  The oracle's autograd (oracle/aclgan_oracle.py) replays an update with these masks in place of its own, which
+ * separates the error of the backward KERNELS from the "mask lottery" (a pre-activation within rounding of zero takes a different branch
+ * in two correct fp32 implementations and moves every upstream gradient).  The dense layers of the MLP are not recorded.  Each call
+ * resets the list; an update whose masks do not fit returns ACLGAN_ENOMEM.  Costs one small launch per block while on. */
+int aclgan_debug_capture_masks(aclgan_ctx* ctx, unsigned char* dst, size_t cap_bytes);
+int aclgan_debug_mask_count(const aclgan_ctx* ctx);
+int aclgan_debug_mask_info(const aclgan_ctx* ctx, int index, int* dims4, long long* offset, int* act);
+
 /* flat parameter buffers.  Tensors are laid out back to back in the reference's
  * `parameters()` order (gen: gen_AB then gen_BA; dis: dis_A, dis_B, dis_2 -- trainer.py:37-38). */
 int64_t aclgan_group_numel(const aclgan_ctx* ctx, int group);
@@ -211,7 +223,7 @@ int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int 
  * (3,B,style_dim) = z_1,z_2,z_3 (trainer.py:99-101).  losses: device float[ACLGAN_L_COUNT].
  * Streams (round 5): the work is ordered after everything already enqueued on `stream` and complete, for `stream`, when the call's last
  * enqueue is (a consumer ordered after `stream` sees the finished update) -- but inside the call independent branches of the update run on
- * up to three more streams of a process-wide pool and the parameter gradients on a fourth ("lanes", aclgan_tuning "lanes"; 1 = `stream`
+ * up to three more streams of a process-wide pool and the parameter gradients on a fourth ("lanes", aclgan_tuning "lanes", 1 .. 3; 1 = `stream`
  * only plus the parameter-gradient stream).  The calling thread's current HIP device must be the device `stream` belongs to (the pool is
  * per device); two threads may step two contexts on one device concurrently (their work interleaves on the pooled streams, ordered by
  * each update's own events), one context is used by one thread at a time.  On an error return every internal stream has been drained. */
@@ -340,6 +352,10 @@ int aclgan_set_tuning(const char* key, int value);
 /* The same switches with the status in the return value (round 5): ACLGAN_OK and the previous setting through *previous (may be NULL), or
  * ACLGAN_EINVAL for an unknown key (aclgan_set_tuning cannot tell -1 "unknown" from a previous value). */
 int aclgan_tuning(const char* key, int value, int* previous);
+/* Read a switch without touching it (round 6; no state change, no tuning-epoch bump): keys "lanes", "u_batch", "norm_mask", "wino_fused",
+ * "wino_wgrad_fused", "fault_at", and "epoch" = the number of aclgan_tuning calls so far (cached switch-dependent results -- an arena
+ * size -- are valid for one epoch).  ACLGAN_EINVAL for any other key. */
+int aclgan_tuning_get(const char* key, long long* value);
 /* The same launch with the normalisation statistics taken from its epilogue (round 3; replaces the norm_stats pass over y that
  * follows the conv in reference networks.py:382-395 Conv2dBlock.forward -> self.norm).  aclgan_conv2d_fwd16s_stats_chunk = rows R per
  * statistics chunk (the launch's row tile: 128 or 256; 0 = not offered: Ho * Wo must be a multiple of R).  stats receives

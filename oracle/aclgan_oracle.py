@@ -189,7 +189,46 @@ def test_nets(hp: dict, seed: int = 0) -> Dict[str, Params]:
 # blocks (networks.py:312-371, 477-536)
 # --------------------------------------------------------------------------------------
 
+# Activation-mask hook (test infrastructure for tests/test_gpu_maskfrozen.py; NOT reference behaviour).  Two correct fp32 implementations
+# of this step disagree on the branch of a ReLU / LeakyReLU wherever a pre-activation lies within rounding of zero, and every such flip moves
+# all upstream gradients ("mask lottery").  Inside `with act_masks(replay) as rec:` every activation of a Conv2dBlock (call i of _act, in
+# call order) records its own mask (x > 0) in rec.recorded[i] and, when replay holds an entry i, APPLIES that mask instead: relu(x) = x * m,
+# lrelu(x) = where(m, x, 0.2 x), with m treated as a constant by autograd -- the backward then runs with exactly the masks the HIP update
+# ran with (include/aclgan_hip.h: aclgan_debug_capture_masks), and what remains is the error of the backward kernels themselves.
+_MASK_HOOK = None
+
+
+class act_masks:
+    def __init__(self, replay=None):
+        self.replay = dict(replay or {})
+        self.recorded = []
+
+    def __enter__(self):
+        global _MASK_HOOK
+        self._prev = _MASK_HOOK
+        _MASK_HOOK = self
+        return self
+
+    def __exit__(self, *a):
+        global _MASK_HOOK
+        _MASK_HOOK = self._prev
+
+    def apply(self, x, act):
+        i = len(self.recorded)
+        own = (x > 0).detach()
+        self.recorded.append(own)
+        m = self.replay.get(i)
+        if m is None:
+            m = own
+        assert m.shape == x.shape, (i, tuple(m.shape), tuple(x.shape))
+        if act == "relu":
+            return torch.where(m, x, torch.zeros_like(x))
+        return torch.where(m, x, 0.2 * x)
+
+
 def _act(x, act):
+    if _MASK_HOOK is not None and act in ("relu", "lrelu"):
+        return _MASK_HOOK.apply(x, act)
     if act == "relu":
         return F.relu(x)
     if act == "lrelu":

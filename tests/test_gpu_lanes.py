@@ -191,3 +191,51 @@ def test_injected_backward_fault_leaves_nothing_in_flight(L):
     finally:
         _tune(L, b"fault_at", -1)
         L.check(L.lib.aclgan_set_deterministic(prev_det))
+
+
+def test_forward_only_call_after_an_update_is_not_refused(L):
+    """advisor, round 5: the arena check of a forward-only call (encode / decode / sample: no side stack, an arena sized by
+    aclgan_forward_workspace_bytes) compared against the side-stream high-water mark the PREVIOUS update had left behind, so a trained
+    context refused an inference call at a new shape with a spurious ACLGAN_ENOMEM.  fwd_begin and the dry runs now reset that mark."""
+    from aclgan_amd.trainer import aclgan_Trainer
+    cfg, nets, x_a, x_b, z = _fixture(S=128, B=2)
+    tr = aclgan_Trainer(cfg)
+    for name in O.OracleTrainer.NETS:
+        getattr(tr, name).load_state_dict(nets[name], strict=False)
+    tr.dis_update(x_a, x_b, cfg, z=z[:3]); tr.gen_update(x_a, x_b, cfg, z=z[3:])
+    torch.cuda.synchronize()
+    # a NEW shape: the trainer binds an arena of exactly the forward-only size (+ nothing for a side stack)
+    tr._ws = None; tr._ws_shape = None
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(1, 3, 192, 160, generator=g) * 2 - 1).cuda()
+    c, s = tr.gen_AB.encode(x)
+    y = tr.gen_AB.decode(c, s)
+    outs = tr.dis_A(x)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 4, 192, 160) and len(outs) == 3 and torch.isfinite(y).all()
+    with torch.no_grad():
+        c_ref, s_ref = O.gen_encode(nets["gen_AB"], x.cpu(), cfg["gen"])
+    assert ((c.cpu() - c_ref).abs().max() / c_ref.abs().max()).item() < 1e-4
+
+
+def test_trainer_sizes_its_arena_again_after_a_tuning_change(L):
+    """advisor, round 5: the trainer cached its arena by shape only; after aclgan_tuning raised the need of an update (more lanes) every
+    update failed with ACLGAN_ENOMEM.  The cache is now keyed by the tuning epoch (aclgan_tuning_get "epoch")."""
+    from aclgan_amd.trainer import aclgan_Trainer
+    cfg, nets, x_a, x_b, z = _fixture(S=64, B=2, narrow=True)
+    old = _tune(L, b"lanes", 1)
+    try:
+        tr = aclgan_Trainer(cfg)
+        for name in O.OracleTrainer.NETS:
+            getattr(tr, name).load_state_dict(nets[name], strict=False)
+        tr.dis_update(x_a, x_b, cfg, z=z[:3])
+        n1 = tr._ws.numel()
+        v = C.c_longlong(); L.check(L.lib.aclgan_tuning_get(b"lanes", C.byref(v)), "tuning_get"); assert v.value == 1
+        _tune(L, b"lanes", 3)
+        tr.dis_update(x_a, x_b, cfg, z=z[:3]); tr.gen_update(x_a, x_b, cfg, z=z[3:])      # (ACLGAN_ENOMEM before the fix)
+        torch.cuda.synchronize()
+        assert tr._ws.numel() >= n1
+        L.check(L.lib.aclgan_tuning_get(b"lanes", C.byref(v)), "tuning_get"); assert v.value == 3
+        assert L.lib.aclgan_tuning_get(b"no_such_key", C.byref(v)) != 0
+    finally:
+        _tune(L, b"lanes", old)

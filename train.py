@@ -107,6 +107,7 @@ def main():
         for _ in range(steps_per_epoch):
             yield ((torch.rand(B, 3, H, W, generator=gen) * 2 - 1).cuda(), (torch.rand(B, 3, H, W, generator=gen) * 2 - 1).cuda())
 
+    batches_per_pass = steps_per_epoch
     if opts.synthetic:
         epoch = synthetic_epoch
         if is_main:
@@ -127,6 +128,7 @@ def main():
             train_loader_a.set_epoch(done); train_loader_b.set_epoch(done)
             epoch0 = done
         epoch = lambda: zip(train_loader_a, train_loader_b)                      # train.py:66
+        batches_per_pass = max(1, min(len(train_loader_a), len(train_loader_b)))
         if is_main:
             print("data: %d / %d training images, device input pipeline, %d rank(s) x batch %d" % (len(train_loader_a.source), len(train_loader_b.source), world, B))
     from aclgan_amd.train_loop import run_epochs, snapshot_due, log_due
@@ -142,8 +144,11 @@ def main():
                            if n in ("loss_gen_total", "loss_dis_total", "loss_idt_A", "loss_gen_adv_A")))
         if is_main and snapshot_due(iterations, config):      # replicas are identical: rank 0's copy is THE checkpoint
             trainer.save(checkpoint_directory, iterations)
+            # "epoch": the pass a resumed run starts with -- the NEXT one when this snapshot falls on the last batch of a pass (a resume used to
+            # replay the finished pass); "it": the per-pass index of this iteration (a resume inside a pass restarts that pass's permutation)
             with open(state_path, "w") as f:
-                json.dump({"seed": seed, "epoch": info["epoch"], "iterations": iterations + 1}, f)
+                json.dump({"seed": seed, "epoch": info["epoch"] + (1 if info["it"] + 1 >= batches_per_pass else 0), "it": info["it"],
+                           "iterations": iterations + 1}, f)
         clock["t0"] = time.time()
 
     last = {"epoch": epoch0}
