@@ -72,6 +72,7 @@ int make_geom(const aclgan_conv_desc* d, ConvGeom* g);
 
 // ---- kernel launchers (all async on `st`) ----
 int conv_fold(const ConvGeom& g, const float* dxp, float* dx, int accumulate, hipStream_t st);
+int conv_fold_band(const ConvGeom& g, const float* dxp, float* dx, int band, hipStream_t st);      // dx += the band (width `band`) of a padded-grid gradient
 bool conv_wgrad_fast_supported(const ConvGeom& g);
 // scratch (optional, conv_fwd_scratch_bytes): enables the sub-pixel path of the upsample+5x5 decoder convs
 int conv_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st, void* scratch = nullptr, float* stats = nullptr,
@@ -241,7 +242,8 @@ int norm_bwd_ln_params(const float* sbc, int B, int C, float* dgamma, float* dbe
 int act_bwd_inplace(int act, const void* y, void* dy, int64_t n, hipStream_t st, int yst = 0, int gst = 0);
 // dst (storage dst_st) = src (storage src_st), elementwise conversion; n % 4 == 0
 int cast_storage(const void* src, int src_st, void* dst, int dst_st, int64_t n, hipStream_t st);
-int positive_mask(const void* y, int yst, unsigned char* dst, int64_t n, hipStream_t st);      // dst[i] = y[i] > 0 (diagnostics)
+int positive_mask(const void* y, int yst, unsigned char* dst, int64_t n, hipStream_t st);
+int positive_mask_diff(const float* a, int ca, const float* b, int cb, unsigned char* dst, int64_t npix, hipStream_t st);      // dst[i] = y[i] > 0 (diagnostics)
 int avgpool3s2_fwd(int B, int H, int W, int C, const float* x, float* y, hipStream_t st);
 int avgpool3s2_bwd(int B, int H, int W, int C, const float* dy, float* dx, int accumulate, hipStream_t st);
 int adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const aclgan_adam* o, int step, hipStream_t st);

@@ -489,6 +489,54 @@ __global__ void conv_fold_kernel(FoldP f) {
     for (int t = 0; t < V; ++t) o[t] = f.accumulate ? o[t] + acc[t] : acc[t];
 }
 
+// Round 6: the same gather restricted to a BAND of the padded grid (sub-pixel layers, conv_up5_dgrad): only the padded positions within
+// `band` of the border hold values (one plain store each by the ring launch, nothing else of dxp is ever written or read), only the dx
+// pixels that alias into the band are touched, and they are always accumulated (the phase launches wrote dx before).  Replaces the
+// ring launch's fp32 atomics (6.2 M per launch on the 256 -> 128 layer: 445 us for 13 GFLOP; one-queue trace of round 5).
+__global__ void conv_fold_band_kernel(FoldP f, int band) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= f.total) return;
+    const int cv = f.Ci / 4;
+    const int c = (int)(idx % cv) * 4;
+    int64_t pix = idx / cv;
+    const int j = (int)(pix % f.Wi); pix /= f.Wi;
+    const int i = (int)(pix % f.Hi);
+    const int b = (int)(pix / f.Hi);
+    const int nu = f.up ? 2 : 1;
+    // low-res pixels none of whose aliases lies in the band: main alias u + p >= band on both sides (the mirrored aliases belong to u <= p)
+    const int bw = ((band - f.p) + nu - 1) / nu;
+    if (i >= bw && i < f.Hi - bw && j >= bw && j < f.Wi - bw) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int du = 0; du < nu; ++du) {
+        int qy[3];
+        const int ny = fold_aliases((i << f.up) + du, f.Hu, f.p, qy);
+        for (int dv = 0; dv < nu; ++dv) {
+            int qx[3];
+            const int nx = fold_aliases((j << f.up) + dv, f.Wu, f.p, qx);
+            for (int a = 0; a < ny; ++a)
+                for (int e = 0; e < nx; ++e) {
+                    if (!(qy[a] < band || qy[a] >= f.Hp - band || qx[e] < band || qx[e] >= f.Wp - band)) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(f.dxp + ((size_t)(b * f.Hp + qy[a]) * f.Wp + qx[e]) * f.Ci + c);
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                }
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(f.dx + ((size_t)(b * f.Hi + i) * f.Wi + j) * f.Ci + c);
+    float4 ov = *o;
+    ov.x += acc[0]; ov.y += acc[1]; ov.z += acc[2]; ov.w += acc[3];
+    *o = ov;
+}
+int conv_fold_band(const ConvGeom& g, const float* dxp, float* dx, int band, hipStream_t st) {
+    if (g.Ci % 4 != 0) { set_error("conv_fold_band: Cin must be a multiple of 4"); return ACLGAN_EINVAL; }
+    FoldP f;
+    f.dxp = dxp; f.dx = dx; f.B = g.B; f.Hi = g.Hi; f.Wi = g.Wi; f.Ci = g.Ci; f.Hu = g.Hu; f.Wu = g.Wu;
+    f.Hp = g.Hp; f.Wp = g.Wp; f.p = g.p; f.up = g.up; f.accumulate = 1;
+    f.total = (int64_t)g.B * g.Hi * g.Wi * (g.Ci / 4);
+    hipLaunchKernelGGL(conv_fold_band_kernel, dim3((unsigned)cdiv64(f.total, 256)), dim3(256), 0, st, f, band);
+    ACL_CHECK_LAUNCH("conv_fold_band_kernel");
+    return ACLGAN_OK;
+}
+
 size_t conv_dgrad_scratch_bytes(const ConvGeom& g) {
     // padded-grid gradient (general path) or the merged phase weights (sub-pixel path), whichever is larger
     return std::max(std::max((size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float), conv_up5_dgrad_scratch_bytes(g)),

@@ -463,7 +463,7 @@ int launch_dgrad_fast(const ConvGeom& g, DgFP p, hipStream_t st) {
     // halo launches loop over the useful taps only (about 1 / taps-per-axis of them): plan the slices for that shorter loop --
     // every slice ends in 128 x 128 fp32 atomics, which is what the old 15-slice halo launch mostly consisted of
     const int nk_plan = (p.mode == 2 && p.band == 0) ? std::max(g.Co / 16, nk_min / ((g.k + g.s - 1) / g.s)) : nk_min;
-    if (nblk < 128 && nk_plan >= 32 && !deterministic())       // (the slices combine with fp32 atomics)
+    if (nblk < 128 && nk_plan >= 32 && !deterministic() && !p.ringpad)       // (the slices combine with fp32 atomics; ringpad: one plain store per position)
         p.ksplit = max(1, min(nk_plan / 8, 512 / nblk));   // floor: stay within one round of 512 resident workgroups
     if (p.ksplit > 1 && p.mode == 0) {
         hipError_t e = hipMemsetAsync(p.dxp, 0, conv_dgrad_scratch_bytes(g), st);
@@ -1014,6 +1014,12 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
     return kc ? launch_wgrad_kc_any(g, p, part, st) : launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
 }
 
+// ACLGAN_UP5_BANDFOLD=0: the ring of the sub-pixel input gradient back on fp32 atomics (round-5 behaviour; A/B switch)
+bool up5_band_fold() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_UP5_BANDFOLD"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v == 1;
+}
 template <int WM, int WN, int TM, int TN>
 int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, float* wp, hipStream_t st) {
     const int64_t nm = (int64_t)4 * g.Co * 9 * (g.Ci / 4);
@@ -1057,6 +1063,15 @@ int up5_dgrad_t(const ConvGeom& g, const float* dy, const float* w, float* dx, i
         if (rc) return rc;
         return conv_fold(g, dxp, dx, 1, st);
     }
+    if (up5_band_fold() && g.Ci % 4 == 0) {
+        // Round 6: one plain store per band position into the (otherwise untouched) padded hi-res scratch, then a gather over the dx pixels
+        // that alias into the band -- instead of 6.2 M fp32 atomics per launch (256 -> 128 layer at 256x256 B=8: 445 us for 13 GFLOP)
+        float* dxp = (float*)((char*)wp + up5_merged_bytes(g));
+        p.ringpad = 1; p.dxp = dxp; p.accumulate = 0;
+        const int rc = launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
+        if (rc) return rc;
+        return conv_fold_band(g, dxp, dx, 6, st);
+    }
     return launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
 }
 
@@ -1069,7 +1084,7 @@ size_t conv_up5_scratch_bytes(const ConvGeom& g) {
 // dgrad of a sub-pixel layer: merged phase filters, then the Winograd planes of its four phases
 size_t conv_up5_dgrad_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled() || !up5_eligible(g)) return 0;
-    const size_t padded = deterministic() ? (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float) : 0;     // ordered ring fold
+    const size_t padded = (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float);     // ring positions on the padded hi-res grid (ordered fold / band fold)
     return up5_merged_bytes(g) + std::max(conv_up5_wino_dgrad_scratch_bytes(g), padded);
 }
 // weight-gradient scratch of the tuned kernels: phase gradients of the sub-pixel layers + the partial tiles of the

@@ -1448,6 +1448,28 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     float* ftot = nullptr;
     if (c.sync_fn) { ftot = c.allocf(8); NEED(ftot); }
     for (int i = 0; i < 3 && focus; ++i) RUN(focus_sums(fl[i].a->d, npix, hp.focus_epsilon, hp.focus_upper, sums + (size_t)i * nfs, c.st));
+    if (c.mask_dst && !c.dry) {
+        // diagnostics (aclgan_debug_capture_masks): the step's two other sign decisions -- |m - 0.5| of the focus digit losses (act code 100: the
+        // sign of the whole 4-channel decoder output, channel 3 = 2 m - 1) and |x_recon - x| of the identity losses (act code 101, 3 channels)
+        auto cap = [&](int code, int C_, size_t n) -> int {
+            if (c.mask_top + n > c.mask_cap) { set_error("aclgan_debug_capture_masks: buffer too small (%zu bytes)", c.mask_cap); return ACLGAN_ENOMEM; }
+            c.mask_log.push_back(aclgan_ctx::MaskEnt{B, H, W, C_, code, (long long)c.mask_top});
+            c.mask_top += n;
+            return ACLGAN_OK;
+        };
+        for (int i = 0; i < 3 && focus; ++i) {
+            const size_t n = (size_t)fl[i].a->numel();
+            unsigned char* dst = c.mask_dst + c.mask_top;
+            CHK(cap(100, fl[i].a->C, n));
+            RUN(positive_mask(fl[i].a->d, fl[i].a->dt, dst, (int64_t)n, c.st));
+        }
+        Act* rr[2] = {rA4, rB4}; Act* xx[2] = {xa, xb};
+        for (int i = 0; i < 2; ++i) {
+            unsigned char* dst = c.mask_dst + c.mask_top;
+            CHK(cap(101, 3, (size_t)npix * 3));
+            RUN(positive_mask_diff(rr[i]->d, rr[i]->C, xx[i]->d, 3, dst, npix, c.st));
+        }
+    }
     c.count(4.0 * (double)npix * ((focus ? 3 * 2 : 0) + 2 * (4 + 3 + 4)));     // focus masks read + gradient written; L1: decoder output, image, gradient
     if (ftot && focus) {
         RUN(focus_totals(sums, npix, 3, ftot, c.st));

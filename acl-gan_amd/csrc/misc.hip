@@ -79,6 +79,21 @@ int positive_mask(const void* y, int yst, unsigned char* dst, int64_t n, hipStre
     return ACLGAN_OK;
 }
 
+// dst[pix][ch] = a[pix][ch] > b[pix][ch] for the first cb channels (a: ca channels per pixel): the sign of the identity loss's |x_recon - x|
+__global__ void positive_mask_diff_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb, unsigned char* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / cb; const int ch = (int)(i - pix * cb);
+        dst[i] = a[pix * ca + ch] > b[pix * cb + ch];
+    }
+}
+int positive_mask_diff(const float* a, int ca, const float* b, int cb, unsigned char* dst, int64_t npix, hipStream_t st) {
+    const int64_t n = npix * cb;
+    if (n == 0) return ACLGAN_OK;
+    hipLaunchKernelGGL(positive_mask_diff_kernel, dim3((int)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, st, a, ca, b, cb, dst, n);
+    ACL_CHECK_LAUNCH("positive_mask_diff_kernel");
+    return ACLGAN_OK;
+}
+
 // ---- storage conversion (fp32 <-> bf16 / fp16), four elements per thread ----
 __global__ void cast_storage_kernel(const void* __restrict__ src, int sst, void* __restrict__ dst, int dst_st, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) st_st4(dst, i, st_ld4(src, i, sst), dst_st);

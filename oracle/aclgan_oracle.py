@@ -199,9 +199,13 @@ _MASK_HOOK = None
 
 
 class act_masks:
-    def __init__(self, replay=None):
+    def __init__(self, replay=None, replay_signs=None):
         self.replay = dict(replay or {})
         self.recorded = []
+        # the step's other two sign decisions: |m - 0.5| of the focus "digit" loss (trainer.py:151) and |x_recon - x| of the identity losses
+        # (trainer.py:162-165): call j of _abs records (d > 0) in signs[j] and applies replay_signs[j] instead when given
+        self.replay_signs = dict(replay_signs or {})
+        self.signs = []
 
     def __enter__(self):
         global _MASK_HOOK
@@ -224,6 +228,21 @@ class act_masks:
         if act == "relu":
             return torch.where(m, x, torch.zeros_like(x))
         return torch.where(m, x, 0.2 * x)
+
+
+def _abs(d):
+    """|d| at the step's two non-smooth loss sites (see act_masks)"""
+    if _MASK_HOOK is None:
+        return torch.abs(d)
+    h = _MASK_HOOK
+    j = len(h.signs)
+    own = (d > 0).detach()
+    h.signs.append(own)
+    m = h.replay_signs.get(j)
+    if m is None:
+        m = own
+    assert m.shape == d.shape, (j, tuple(m.shape), tuple(d.shape))
+    return torch.where(m, d, -d)
 
 
 def _act(x, act):
@@ -570,7 +589,7 @@ def focus_losses(focus, hp):
     m = (focus + 1) / 2
     size = (F.relu(torch.sum(m - hp["focus_upper"])) ** 2) * hp["focus_delta"] + \
            (F.relu(torch.sum(hp["focus_lower"] - m)) ** 2) * hp["focus_delta"]
-    digit = torch.sum(1 / (torch.abs(m - 0.5) + hp["focus_epsilon"]))
+    digit = torch.sum(1 / (_abs(m - 0.5) + hp["focus_epsilon"]))
     return size, digit
 
 
@@ -634,8 +653,8 @@ def gen_losses(nets: Dict[str, Params], x_a, x_b, z, hp):
         L["loss_gen_focus_A2_size"], L["loss_gen_focus_A2_digit"] = sA2, dA2
         B, _, H, W = x_a.shape
         total = total + hp["focus_loss"] * (sB + dB + sA + dA + sA2 + dA2) / H / W / B / 3
-    L["loss_idt_A"] = torch.mean(torch.abs(fw["x_A_recon"] - x_a))
-    L["loss_idt_B"] = torch.mean(torch.abs(fw["x_B_recon"] - x_b))
+    L["loss_idt_A"] = torch.mean(_abs(fw["x_A_recon"] - x_a))
+    L["loss_idt_B"] = torch.mean(_abs(fw["x_B_recon"] - x_b))
     total = total + hp["recon_x_w"] * L["loss_idt_A"] + hp["recon_x_w"] * L["loss_idt_B"]
     L["loss_gen_total"] = total
     return total, L, fw

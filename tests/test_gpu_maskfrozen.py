@@ -4,8 +4,8 @@ The step-level gradient tests (tests/test_gpu_fullsize.py: every gradient tensor
 5 - 6e-3) cannot tell a sloppy backward kernel from the "mask lottery": two correct fp32 implementations take different branches of a
 ReLU / LeakyReLU wherever a pre-activation lies within forward rounding (~1e-5) of zero, and every flipped element moves all upstream
 gradients.  Here the lottery is taken out: the HIP update records the masks it ran with (aclgan_debug_capture_masks: output > 0 of every
-Conv2dBlock it back-propagates through), the oracle's autograd replays the same update with THOSE masks in place of its own
-(oracle.act_masks), and what is left is the error of the backward kernels themselves (summation order, Winograd transforms, atomics):
+Conv2dBlock it back-propagates through, plus the step's two other sign decisions: |m - 0.5| of the focus digit losses and |x_recon - x| of
+the identity losses), the oracle's autograd replays the same update with THOSE masks in place of its own (oracle.act_masks), and what is left is the error of the backward kernels themselves (summation order, Winograd transforms, atomics):
 
     fp32   every gradient tensor <= 1e-3 relative L2 (the un-frozen figure of the same run is printed beside it)
     bf16 / fp16 against the EMULATED 16-bit contract (oracle.compute_dtype) with the masks frozen: per network bounds below.
@@ -56,17 +56,22 @@ def _hip_update_with_masks(tr, which, x_a, x_b, cfg, z, B, cap_bytes):
     try:
         (tr.dis_update if which == "dis" else tr.gen_update)(x_a, x_b, cfg, z=z)
         torch.cuda.synchronize()
-        chunks = []
+        chunks, signs = [], []
         dims = (C.c_int * 4)(); off = C.c_longlong(); act = C.c_int()
         for i in range(L.lib.aclgan_debug_mask_count(tr._ctx)):
             L.check(L.lib.aclgan_debug_mask_info(tr._ctx, i, dims, C.byref(off), C.byref(act)), "debug_mask_info")
             b, h, w, c = list(dims)
             m = buf[off.value: off.value + b * h * w * c].view(b, h, w, c).permute(0, 3, 1, 2).bool().cpu()
-            assert b % B == 0, (b, B)
-            chunks.extend(m[j:j + B] for j in range(0, b, B))
+            if act.value == 100:        # sign of a focus mask's (m - 0.5): channel 3 of the decoder output (2 m - 1)
+                signs.append(m[:, 3:4].contiguous())
+            elif act.value == 101:      # sign of (x_recon - x) of an identity loss
+                signs.append(m.contiguous())
+            else:
+                assert b % B == 0, (b, B)
+                chunks.extend(m[j:j + B] for j in range(0, b, B))
     finally:
         L.check(L.lib.aclgan_debug_capture_masks(tr._ctx, None, 0), "debug_capture_masks(off)")
-    return chunks
+    return chunks, signs
 
 
 def _match(recorded, chunks):
@@ -125,19 +130,22 @@ def _frozen_and_free(T, dt, B, S, seed):
         tr = _make(T, cfg, nets, dt)
         if dt:
             assert tr.grad_scale() == scale
-        chunks = _hip_update_with_masks(tr, which, x_a, x_b, cfg, zz, B, 2 << 30 if S >= 256 else 1 << 29)
+        chunks, signs = _hip_update_with_masks(tr, which, x_a, x_b, cfg, zz, B, 2 << 30 if S >= 256 else 1 << 29)
         assert chunks, "nothing recorded"
+        assert len(signs) == (5 if which == "gen" else 0), len(signs)      # focus B, A, A2 + identity A, B: the oracle's call order (gen_losses)
         with ctx(), O.act_masks() as rec:                    # the oracle with its OWN masks
             free = O.OracleTrainer(cfg, nets=nets)
             (free.dis_update if which == "dis" else free.gen_update)(x_a, x_b, zz, apply=False)
         replay, flips, total, unmatched = _match(rec.recorded, chunks)
-        with ctx(), O.act_masks(replay) as rec2:             # ... and with the masks of the HIP update
+        sflips = sum(int((a != b).sum()) for a, b in zip(signs, rec.signs))
+        with ctx(), O.act_masks(replay, dict(enumerate(signs))) as rec2:             # ... and with the masks / signs of the HIP update
             frozen = O.OracleTrainer(cfg, nets=nets)
             (frozen.dis_update if which == "dis" else frozen.gen_update)(x_a, x_b, zz, apply=False)
         assert len(rec2.recorded) == len(rec.recorded)
         e_free, e_frozen = _grad_errors(tr, free, nets_, scale), _grad_errors(tr, frozen, nets_, scale)
         print("%s %s_update @%dx%d B=%d: %d of %d oracle activations matched to a recorded mask (%d recorded chunks), %d of %d mask elements differ (%.2e)"
               % (dt or "fp32", which, S, S, B, len(replay), len(rec.recorded), len(chunks), flips, total, flips / max(1, total)))
+        print("   sign decisions of the focus digit / identity losses that differ: %d of %d" % (sflips, sum(a.numel() for a in signs)))
         print("   unmatched oracle activations (no gradient passes through them in the HIP update):", unmatched[:8], "..." if len(unmatched) > 8 else "")
         print("   worst gradient tensors, masks FROZEN:", [("%.2e" % e, n, k) for e, n, k in e_frozen[:4]])
         print("   worst gradient tensors, masks free  :", [("%.2e" % e, n, k) for e, n, k in e_free[:4]])
