@@ -230,6 +230,31 @@ __device__ __forceinline__ bool dg_row(const DgFP& p, int m, int ylo, int yhi, i
     // inside one strip (except at the three seams), so the per-tile tap list of a halo launch holds the k taps that strip can see
     // instead of the union over the strips of one image (3x3, pad 1: 3 taps instead of 6-8 -- the tile's k loop is that much shorter).
     // Side strips are column-major for the same reason (wide bands of the sub-pixel layers: one or two x positions per tile).
+    if (p.band > 0 && ny > 0 && nx > 0) {
+        // Wide bands (the ring launch of the sub-pixel layers; round 6).  A tile's k loop runs over the UNION of the filter taps its rows can
+        // see (tap_list), and with the strips above every top / bottom tile contained corner columns (which see the taps of BOTH directions:
+        // up to all 25) and two padded rows: 5 - 25 taps per tile, the launch as slow as its slowest tiles (445 us for 13 GFLOP on the 256 -> 128
+        // layer).  Now: the four corners first (the only tiles that need many taps: scheduled first), then each strip ordered so that a tile
+        // holds ONE padded row (column) across the images of the batch: ty in {r - 1, r} x 5 tx = 10 taps (5 at the outermost / innermost row).
+        const int bt = p.Hc - 1 - yhi, rt = p.Wc - 1 - xhi;            // bottom rows, right columns
+        const int tb = ylo + bt, lr = xlo + rt, Cn = tb * lr;
+        if (m < p.B * Cn) {
+            b = m / Cn; const int r = m - b * Cn; const int cy_ = r / lr, cx_ = r - cy_ * lr;
+            y2 = cy_ < ylo ? cy_ : yhi + 1 + (cy_ - ylo); x2 = cx_ < xlo ? cx_ : xhi + 1 + (cx_ - xlo);
+            return true;
+        }
+        m -= p.B * Cn;
+        const int rowlen = p.B * nx, collen = p.B * ny;
+        if (m < ylo * rowlen) { const int t = m / rowlen, r = m - t * rowlen; b = r / nx; y2 = t; x2 = xlo + r - b * nx; return true; }
+        m -= ylo * rowlen;
+        if (m < bt * rowlen) { const int t = m / rowlen, r = m - t * rowlen; b = r / nx; y2 = yhi + 1 + t; x2 = xlo + r - b * nx; return true; }
+        m -= bt * rowlen;
+        if (m < xlo * collen) { const int t = m / collen, r = m - t * collen; b = r / ny; x2 = t; y2 = ylo + r - b * ny; return true; }
+        m -= xlo * collen;
+        if (m >= rt * collen) return false;
+        { const int t = m / collen, r = m - t * collen; b = r / ny; x2 = xhi + 1 + t; y2 = ylo + r - b * ny; }
+        return true;
+    }
     const int top = min(ylo, p.Hc) * p.Wc, bot = min(p.Hc - 1 - yhi, p.Hc - min(ylo, p.Hc)) * p.Wc, left = max(ny, 0) * xlo;
     const int right = R - top - bot - left;
     if (top > 0 && m < p.B * top) { b = m / top; const int r = m - b * top; y2 = r / p.Wc; x2 = r - y2 * p.Wc; return true; }

@@ -363,15 +363,19 @@ struct aclgan_ctx {
             if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) capturing = true;
             else (void)hipGetLastError();
         }
-        if (capturing) nlanes = 1;
+        // ACLGAN_CAPTURE_LANES=1 (investigation switch, round 6): capture the pooled lanes as they are
+        static int cap_lanes = -1;
+        if (cap_lanes < 0) { const char* e = getenv("ACLGAN_CAPTURE_LANES"); cap_lanes = (e && atoi(e)) ? 1 : 0; }
+        const bool cap_one = capturing && !cap_lanes;
+        if (cap_one) nlanes = 1;
         cur_lane = 0; st0 = st;
         for (int l = 0; l < MAXL; ++l) { lane_evs[l].clear(); hw[l] = 0; lane_dirty[l] = false; for (int m = 0; m < MAXL; ++m) seen[l][m] = 0; }
         ev_next = 0;
         if (dry) return ACLGAN_OK;
         // (parameter-gradient stream first, then the lanes: with the caller's stream that is one hardware queue each up to 3 lanes)
         if (side_enabled() && !st2_pool) { int rc = aclgan::StreamPool::of_device().get(0, &st2_pool); if (rc) return rc; }
-        if (side_enabled() && capturing) { int rc = make_private_side(); if (rc) return rc; }
-        st2 = capturing ? st2_private : st2_pool;
+        if (side_enabled() && cap_one) { int rc = make_private_side(); if (rc) return rc; }
+        st2 = cap_one ? st2_private : st2_pool;
         for (int l = 1; l < nlanes; ++l)
             if (!lane_st[l]) { int rc = aclgan::StreamPool::of_device().get(l, &lane_st[l]); if (rc) return rc; }
         return ACLGAN_OK;

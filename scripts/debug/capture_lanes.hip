@@ -1,0 +1,104 @@
+// Minimal reproductions for the round-5 crash "hipStreamEndCapture segfaults when an update with pooled lanes is captured"
+// (acl-gan_amd/csrc/engine.hip lanes_begin: a captured update falls back to one lane).  Every variant builds the stream / event pattern the
+// lane scheduler produces, under stream capture of an origin stream, in a CHILD process (a segfault is reported, not fatal):
+//   hipcc --offload-arch=gfx950 -O2 -o /tmp/capture_lanes scripts/debug/capture_lanes.hip && /tmp/capture_lanes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <unistd.h>
+#include <sys/wait.h>
+
+__global__ void k(float* p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = p[i] * 1.0001f + 1.f; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("    %s -> %s\n", #x, hipGetErrorString(e_)); fflush(stdout); return 1; } } while (0)
+
+static int run(int v, hipStreamCaptureMode mode) {
+    const int N = 1 << 16;
+    float* buf = nullptr;
+    CK(hipMalloc(&buf, 8 * N * sizeof(float)));
+    CK(hipMemset(buf, 0, 8 * N * sizeof(float)));
+    hipStream_t origin, s[4];
+    CK(hipStreamCreateWithFlags(&origin, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) CK(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    std::vector<hipEvent_t> ev(4096);
+    for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int ne = 0;
+    auto K = [&](hipStream_t st, int slot) { hipLaunchKernelGGL(k, dim3(N / 256), dim3(256), 0, st, buf + slot * N, N); return hipGetLastError(); };
+    auto edge = [&](hipStream_t from, hipStream_t to) -> hipError_t { hipEvent_t e = ev[ne++]; hipError_t r = hipEventRecord(e, from); if (r != hipSuccess) return r; return hipStreamWaitEvent(to, e, 0); };
+    if (v == 7) { CK(K(s[1], 1)); CK(hipEventRecord(ev[4000], s[1])); }      // an event recorded BEFORE the capture begins (eager work of the previous step)
+    CK(hipStreamBeginCapture(origin, mode));
+    if (v == 4) CK(hipMemsetAsync(buf + 7 * N, 0, N * sizeof(float), origin));
+    CK(K(origin, 0));
+    switch (v) {
+    case 1: case 4:      // plain fork / join over three lanes
+        for (int l = 0; l < 3; ++l) { CK(edge(origin, s[l])); CK(K(s[l], l + 1)); }
+        for (int l = 0; l < 3; ++l) CK(edge(s[l], origin));
+        break;
+    case 2:      // a lane that only ever receives a wait, joined again
+        CK(edge(origin, s[0])); CK(K(s[0], 1)); CK(edge(origin, s[1]));
+        CK(edge(s[0], origin)); CK(edge(s[1], origin));
+        break;
+    case 3:      // ... and NOT joined again (must be an error code, not a crash)
+        CK(edge(origin, s[0])); CK(K(s[0], 1)); CK(edge(origin, s[1]));
+        CK(edge(s[0], origin));
+        break;
+    case 5: {    // ONE event pair re-recorded for every fork / join of a side stream (ev_fork / ev_join of the engine), 200 times
+        hipEvent_t f = ev[ne++], j = ev[ne++];
+        for (int i = 0; i < 200; ++i) { CK(K(origin, 0)); CK(hipEventRecord(f, origin)); CK(hipStreamWaitEvent(s[3], f, 0)); CK(K(s[3], 4)); }
+        CK(hipEventRecord(j, s[3])); CK(hipStreamWaitEvent(origin, j, 0));
+        break; }
+    case 6:      // cross-lane waits, several waiters on one event, a lane waiting for an OLD checkpoint of another lane
+        CK(edge(origin, s[0])); CK(edge(origin, s[1])); CK(K(s[0], 1)); CK(K(s[1], 2));
+        { hipEvent_t e = ev[ne++]; CK(hipEventRecord(e, s[0])); CK(K(s[0], 1)); CK(hipStreamWaitEvent(s[1], e, 0)); CK(hipStreamWaitEvent(s[2], e, 0)); CK(hipStreamWaitEvent(origin, e, 0)); }
+        CK(K(s[2], 3)); CK(K(s[1], 2));
+        for (int l = 0; l < 3; ++l) CK(edge(s[l], origin));
+        break;
+    case 7:      // a captured stream waits for an event recorded before the capture
+        CK(hipStreamWaitEvent(origin, ev[4000], 0)); CK(edge(origin, s[0])); CK(K(s[0], 2)); CK(edge(s[0], origin));
+        break;
+    case 8: {    // the size of a real update: 2400 kernels over the origin, three lanes and a side stream, a cross edge every 8 launches
+        for (int l = 0; l < 4; ++l) CK(edge(origin, s[l]));
+        for (int i = 0; i < 2400; ++i) {
+            const int l = i % 5; hipStream_t st = l == 4 ? origin : s[l];
+            CK(K(st, l));
+            if (i % 8 == 7) { const int t = (i / 8) % 5; hipStream_t to = t == 4 ? origin : s[t]; if (to != st) CK(edge(st, to)); }
+        }
+        for (int l = 0; l < 4; ++l) CK(edge(s[l], origin));
+        break; }
+    case 9: {    // the join pattern of lanes_join + side_join, then MORE work and a second join (bucket hand-outs in the middle of the backward)
+        for (int r = 0; r < 6; ++r) {
+            for (int l = 0; l < 4; ++l) { CK(edge(origin, s[l])); CK(K(s[l], l + 1)); }
+            for (int l = 0; l < 4; ++l) CK(edge(s[l], origin));
+            CK(K(origin, 0));
+        }
+        break; }
+    default: break;
+    }
+    CK(K(origin, 0));
+    hipGraph_t g = nullptr;
+    CK(hipStreamEndCapture(origin, &g));
+    hipGraphExec_t ge = nullptr;
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, origin));
+    CK(hipStreamSynchronize(origin));
+    size_t nodes = 0; CK(hipGraphGetNodes(g, nullptr, &nodes));
+    printf("    ok: %zu nodes, 3 replays\n", nodes);
+    return 0;
+}
+
+int main() {
+    const char* names[] = {"", "fork/join 3 lanes", "wait-only lane, rejoined", "wait-only lane, NOT rejoined (expect an error code)", "memset on the origin before the fork",
+                           "one event pair re-recorded 200 times", "cross-lane waits, shared event", "wait on an event recorded before the capture",
+                           "2400 kernels, 5 streams, 300 cross edges", "six fork/join rounds with work in between"};
+    for (int mode = 0; mode < 2; ++mode)
+        for (int v = 1; v <= 9; ++v) {
+            printf("[%s] variant %d: %s\n", mode == 0 ? "global" : "thread-local", v, names[v]); fflush(stdout);
+            pid_t pid = fork();
+            if (pid == 0) { const int rc = run(v, mode == 0 ? hipStreamCaptureModeGlobal : hipStreamCaptureModeThreadLocal); fflush(stdout); _exit(rc); }
+            int status = 0; waitpid(pid, &status, 0);
+            if (WIFSIGNALED(status)) printf("    CRASHED: signal %d\n", WTERMSIG(status));
+            else if (WEXITSTATUS(status)) printf("    failed (rc %d)\n", WEXITSTATUS(status));
+            fflush(stdout);
+        }
+    return 0;
+}

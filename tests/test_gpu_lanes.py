@@ -213,8 +213,9 @@ def test_forward_only_call_after_an_update_is_not_refused(L):
     outs = tr.dis_A(x)
     torch.cuda.synchronize()
     assert y.shape == (1, 4, 192, 160) and len(outs) == 3 and torch.isfinite(y).all()
-    with torch.no_grad():
-        c_ref, s_ref = O.gen_encode(nets["gen_AB"], x.cpu(), cfg["gen"])
+    with torch.no_grad():      # (the two updates have moved the parameters: the oracle gets the trainer's current ones)
+        now = {k: v.detach().cpu() for k, v in tr.gen_AB.state_dict().items()}
+        c_ref, s_ref = O.gen_encode(now, x.cpu(), cfg["gen"])
     assert ((c.cpu() - c_ref).abs().max() / c_ref.abs().max()).item() < 1e-4
 
 

@@ -7,7 +7,8 @@ gradients.  Here the lottery is taken out: the HIP update records the masks it r
 Conv2dBlock it back-propagates through, plus the step's two other sign decisions: |m - 0.5| of the focus digit losses and |x_recon - x| of
 the identity losses), the oracle's autograd replays the same update with THOSE masks in place of its own (oracle.act_masks), and what is left is the error of the backward kernels themselves (summation order, Winograd transforms, atomics):
 
-    fp32   every gradient tensor <= 1e-3 relative L2 (the un-frozen figure of the same run is printed beside it)
+    fp32   every gradient tensor <= 1e-3 relative L2 -- measured 1.3e-5 (gen_update) / 2.5e-6 (dis_update) at 256x256 B=2, against 7.2e-3 /
+           4.3e-4 un-frozen in the same run: 398 of 2.5e8 mask elements and ONE of 1.2e6 loss signs differed
     bf16 / fp16 against the EMULATED 16-bit contract (oracle.compute_dtype) with the masks frozen: per network bounds below.
 
 Blocks are matched between the two implementations by CONTENT, not by order (the engine builds the passes of an update in its lane order
@@ -169,14 +170,17 @@ def test_backward_parity_with_frozen_masks_fp32(T):
         r = res[which]
         # every activation a gradient passes through was matched (dis_update: the generator pass is forward-only in the HIP update)
         assert r["matched"] >= (0.3 if which == "dis" else 0.9) * r["acts"], (which, r["matched"], r["acts"], r["unmatched"][:6])
-        assert r["frozen"][0][0] <= 1e-3, (which, r["frozen"][:6])
+        assert r["frozen"][0][0] <= 1e-3, (which, r["frozen"][:6])       # (measured 1.3e-5 / 2.5e-6: the bound of the review; 1e-4 would hold)
         assert r["free"][0][0] <= 1e-2, (which, r["free"][:6])
 
 
-# 16-bit: bounds per network <= 2x the measured value (profiles/r06_experiments.md), masks frozen, against the emulated contract
+# 16-bit: bounds per network group <= 2x the measured value, masks and signs frozen, against the emulated contract.  Measured (round 6,
+# profiles/r06_experiments.md): bf16 dis 7.8e-3, gen.dec 1.82e-2, gen.enc 1.63e-2 (un-frozen: 5.6e-2 / 1.96e-1); fp16 dis 9.2e-4, gen.dec
+# 2.4e-3, gen.enc 2.2e-3 (un-frozen: 2.0e-2 / 7.0e-2) -- what remains is the rounding-flip noise of the 16-bit values themselves
+# (tests/test_gpu_step16.py docstring), 10x below the un-frozen figures the round-5 bounds (3e-1 / 1.2e-1) had to admit.
 ETOL_FROZEN = {
-    "bf16": {"dis": 2e-2, "gen.dec": 2e-2, "gen.enc": 2e-2},
-    "fp16": {"dis": 2e-2, "gen.dec": 2e-2, "gen.enc": 2e-2},
+    "bf16": {"dis": 1.5e-2, "gen.dec": 3e-2, "gen.enc": 3e-2},
+    "fp16": {"dis": 2e-3, "gen.dec": 5e-3, "gen.enc": 5e-3},
 }
 
 
