@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <unistd.h>
 #include <sys/wait.h>
@@ -57,11 +58,13 @@ static int run(int v, hipStreamCaptureMode mode) {
         CK(hipStreamWaitEvent(origin, ev[4000], 0)); CK(edge(origin, s[0])); CK(K(s[0], 2)); CK(edge(s[0], origin));
         break;
     case 8: {    // the size of a real update: 2400 kernels over the origin, three lanes and a side stream, a cross edge every 8 launches
+        //              (CAP_N / CAP_E: number of kernels / launches per cross edge, for the sweep at the end of main)
+        const int nk = getenv("CAP_N") ? atoi(getenv("CAP_N")) : 2400, ep = getenv("CAP_E") ? atoi(getenv("CAP_E")) : 8;
         for (int l = 0; l < 4; ++l) CK(edge(origin, s[l]));
-        for (int i = 0; i < 2400; ++i) {
+        for (int i = 0; i < nk; ++i) {
             const int l = i % 5; hipStream_t st = l == 4 ? origin : s[l];
             CK(K(st, l));
-            if (i % 8 == 7) { const int t = (i / 8) % 5; hipStream_t to = t == 4 ? origin : s[t]; if (to != st) CK(edge(st, to)); }
+            if (i % ep == ep - 1) { const int t = (i / ep) % 5; hipStream_t to = t == 4 ? origin : s[t]; if (to != st) CK(edge(st, to)); }
         }
         for (int l = 0; l < 4; ++l) CK(edge(s[l], origin));
         break; }
@@ -86,7 +89,27 @@ static int run(int v, hipStreamCaptureMode mode) {
     return 0;
 }
 
-int main() {
+static void child(int v, hipStreamCaptureMode mode) {
+    pid_t pid = fork();
+    if (pid == 0) { const int rc = run(v, mode); fflush(stdout); _exit(rc); }
+    int status = 0; waitpid(pid, &status, 0);
+    if (WIFSIGNALED(status)) printf("    CRASHED: signal %d\n", WTERMSIG(status));
+    else if (WEXITSTATUS(status)) printf("    failed (rc %d)\n", WEXITSTATUS(status));
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "sweep")) {      // how large / how connected may a multi-stream capture be?
+        const int ns[] = {100, 200, 400, 800, 1200, 1600, 2400}, es[] = {4, 8, 32, 128, 100000};
+        for (int e : es)
+            for (int n : ns) {
+                char a[32], b[32]; snprintf(a, sizeof a, "%d", n); snprintf(b, sizeof b, "%d", e);
+                setenv("CAP_N", a, 1); setenv("CAP_E", b, 1);
+                printf("[sweep] %d kernels over 5 streams, one cross edge per %d launches\n", n, e); fflush(stdout);
+                child(8, hipStreamCaptureModeThreadLocal);
+            }
+        return 0;
+    }
     const char* names[] = {"", "fork/join 3 lanes", "wait-only lane, rejoined", "wait-only lane, NOT rejoined (expect an error code)", "memset on the origin before the fork",
                            "one event pair re-recorded 200 times", "cross-lane waits, shared event", "wait on an event recorded before the capture",
                            "2400 kernels, 5 streams, 300 cross edges", "six fork/join rounds with work in between"};
