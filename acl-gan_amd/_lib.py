@@ -92,6 +92,7 @@ SIGNATURES = {
     "aclgan_bind_workspace": (ci, [vp, vp, sz]),
     "aclgan_forward_workspace_bytes": (ci, [vp, ci, ci, ci, C.POINTER(sz)]),
     "aclgan_step_algorithmic_bytes": (ci, [vp, ci, ci, ci, ci, C.POINTER(C.c_double)]),
+    "aclgan_step_executed_flops": (ci, [vp, ci, ci, ci, ci, C.POINTER(C.c_double)]),
     "aclgan_gen_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
     "aclgan_dis_update": (ci, [vp, vp, vp, vp, ci, ci, ci, C.POINTER(HParams), vp, vp]),
     "aclgan_set_grad_buckets": (ci, [vp, i64, BUCKET_FN, vp]),

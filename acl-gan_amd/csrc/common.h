@@ -72,6 +72,8 @@ int make_geom(const aclgan_conv_desc* d, ConvGeom* g);
 
 // ---- kernel launchers (all async on `st`) ----
 int conv_fold(const ConvGeom& g, const float* dxp, float* dx, int accumulate, hipStream_t st);
+// matrix-pipe FLOPs the chosen path of this convolution executes (conv_fast.hip; which: 0 forward, 1 input gradient, 2 weight gradient)
+double conv_exec_flops(const ConvGeom& g, int which, bool f16);
 int conv_fold_band(const ConvGeom& g, const float* dxp, float* dx, int band, hipStream_t st);      // dx += the band (width `band`) of a padded-grid gradient
 bool conv_wgrad_fast_supported(const ConvGeom& g);
 // scratch (optional, conv_fwd_scratch_bytes): enables the sub-pixel path of the upsample+5x5 decoder convs

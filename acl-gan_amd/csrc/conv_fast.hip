@@ -1014,10 +1014,13 @@ int up5_wgrad_t(const ConvGeom& g, const float* x, const float* dy, float* dw, f
     return kc ? launch_wgrad_kc_any(g, p, part, st) : launch_wgrad_fast<WM, WN, TM, TN>(g, p, st);
 }
 
-// ACLGAN_UP5_BANDFOLD=0: the ring of the sub-pixel input gradient back on fp32 atomics (round-5 behaviour; A/B switch)
+// ACLGAN_UP5_BANDFOLD=1: the ring of the sub-pixel input gradient as plain stores on the padded hi-res grid + a gather over the dx pixels that
+// alias into the band, instead of fp32 atomics.  MEASURED SLOWER (round 6, profiles/r06_experiments.md): the step 82.9 against 82.3 ms (3 lanes),
+// 90.5 against 90.1 (one queue) -- the ring launch is bound by its k loop and its tail, not by the atomics; the extra launch and the 25 MB
+// round trip cost more than the atomics did.  Off; kept as a measured option (the deterministic mode uses the full-grid fold as before).
 bool up5_band_fold() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("ACLGAN_UP5_BANDFOLD"); v = (e && !atoi(e)) ? 0 : 1; }
+    if (v < 0) { const char* e = getenv("ACLGAN_UP5_BANDFOLD"); v = (e && atoi(e)) ? 1 : 0; }
     return v == 1;
 }
 template <int WM, int WN, int TM, int TN>
@@ -1084,7 +1087,7 @@ size_t conv_up5_scratch_bytes(const ConvGeom& g) {
 // dgrad of a sub-pixel layer: merged phase filters, then the Winograd planes of its four phases
 size_t conv_up5_dgrad_scratch_bytes(const ConvGeom& g) {
     if (!fast_enabled() || !up5_eligible(g)) return 0;
-    const size_t padded = (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float);     // ring positions on the padded hi-res grid (ordered fold / band fold)
+    const size_t padded = (deterministic() || up5_band_fold()) ? (size_t)g.B * g.Hp * g.Wp * g.Ci * sizeof(float) : 0;     // ring positions on the padded hi-res grid (ordered fold / band fold)
     return up5_merged_bytes(g) + std::max(conv_up5_wino_dgrad_scratch_bytes(g), padded);
 }
 // weight-gradient scratch of the tuned kernels: phase gradients of the sub-pixel layers + the partial tiles of the
@@ -1271,6 +1274,57 @@ int conv_wgrad_fast(const ConvGeom& g, const float* x, const float* dy, float* d
     if (g.Co > 64) return launch_wgrad_fast<2, 2, 2, 2>(g, p, st, det);
     if (g.Co > 32) return launch_wgrad_fast<2, 2, 1, 2>(g, p, st, det);
     return launch_wgrad_fast<1, 4, 1, 2>(g, p, st, det);
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: matrix-pipe FLOPs the chosen path of a convolution EXECUTES (which: 0 forward, 1 input gradient, 2 weight gradient; f16: the
+// 16-bit kernels run it) -- the same decisions as the launchers above, counted per launch the way the hardware counts (whole tiles): the
+// model behind roofline.flop_per_launch (aclgan_step_executed_flops), checked against `rocprofv3 --pmc SQ_INSTS_MFMA` (scripts/step_mfma_flops.py).
+//   direct kernels            2 M Co K
+//   Winograd F(4x4,3x3)       36 multiplies per 4x4 output tile and channel pair instead of 144 (fused kernel: whole blocks of 32 tiles x 64 channels)
+//   sub-pixel (up5) layers    four VALID 3x3 phases (Winograd in fp32) + the exact output ring of width 2
+//   4x4 stride-2 layers       four parity phases x 36 per tile when the fused kernel takes them (9 / 16 of the direct MACs)
+// ------------------------------------------------------------------------------------------
+namespace {
+double fused_flops(int B, int OH, int OW, int Cin_, int Cout_, int gph, int kph) {      // wino_fused_go's grid x its K loop
+    const int TY = cdiv(OH, 4), TX = cdiv(OW, 4);
+    const double wgs = (double)B * cdiv(TY, 4) * cdiv(TX, 8) * (Cout_ / 64) * gph;
+    return wgs * 2.0 * 36.0 * 32.0 * 64.0 * (double)Cin_ * kph;
+}
+double pipe_flops(int B, int OH, int OW, int Cin_, int Cout_, int slices) { return 2.0 * 36.0 * slices * (double)B * cdiv(OH, 4) * cdiv(OW, 4) * Cin_ * Cout_; }
+}  // namespace
+double conv_exec_flops(const ConvGeom& g, int which, bool f16) {
+    const double direct = 2.0 * (double)g.M * g.Co * g.K;
+    const double ringpix = (double)g.Ho * g.Wo - (double)std::max(0, g.Ho - 4) * std::max(0, g.Wo - 4);      // output ring of width 2 (sub-pixel layers)
+    if (up5_eligible(g) && fast_enabled()) {
+        const double ring_fwd = 2.0 * g.B * ringpix * g.Co * g.K;
+        // input gradient: band of width 6 of the padded hi-res grid, ~9 of the 25 taps useful per position (tap lists, conv_fast_common.h::dg_row)
+        const double band = (double)g.Hp * g.Wp - (double)std::max(0, g.Hp - 12) * std::max(0, g.Wp - 12);
+        const double ring_dg = 2.0 * g.B * band * g.Ci * g.Co * 9.0;
+        if (!f16 && conv_up5_wino_ok(g)) {
+            if (which == 0) return (wino_fused_ok(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, g.act, 4, 1) ? fused_flops(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, 4, 1)
+                                                                                                     : pipe_flops(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, 4)) + ring_fwd;
+            if (which == 1) return (wino_fused_ok(g.B, g.Hi, g.Wi, g.Co, g.Ci, ACLGAN_ACT_NONE, 1, 4) ? fused_flops(g.B, g.Hi, g.Wi, g.Co, g.Ci, 1, 4)
+                                                                                                       : pipe_flops(g.B, g.Hi, g.Wi, g.Co, g.Ci, 4)) + ring_dg;
+            return (conv_up5_wino_wgrad_scratch_bytes(g) ? pipe_flops(g.B, g.Hi - 2, g.Wi - 2, g.Ci, g.Co, 4) : 4.0 * 2.0 * g.B * (g.Hi - 2.0) * (g.Wi - 2.0) * g.Co * 9.0 * g.Ci) + ring_fwd;
+        }
+        const double phases = 4.0 * 2.0 * g.B * (g.Hi - 2.0) * (g.Wi - 2.0) * g.Co * 9.0 * g.Ci;
+        return phases + (which == 1 ? ring_dg : ring_fwd);
+    }
+    if (!f16 && fast_enabled() && g.Ci % 16 == 0 && conv_wino_ok(g)) {
+        const double halo = 2.0 * g.B * ((double)g.Hp * g.Wp - (double)g.Hi * g.Wi) * g.Ci * g.Co * 3.0;      // ring of the padded grid, 3 of 9 taps per position
+        if (which == 0) return wino_fused_ok(g.B, g.Hi, g.Wi, g.Ci, g.Co, g.act) && !conv_fwd_keep_bytes(g) ? fused_flops(g.B, g.Hi, g.Wi, g.Ci, g.Co, 1, 1)
+                                                                                                              : pipe_flops(g.B, g.Hi, g.Wi, g.Ci, g.Co, 1);
+        if (which == 1) return (wino_fused_ok(g.B, g.Hi, g.Wi, g.Co, g.Ci, ACLGAN_ACT_NONE) ? fused_flops(g.B, g.Hi, g.Wi, g.Co, g.Ci, 1, 1) : pipe_flops(g.B, g.Hi, g.Wi, g.Co, g.Ci, 1)) + halo;
+        if (wgrad_kc_ok(g) && conv_wgrad_wino_scratch_bytes(g)) return pipe_flops(g.B, g.Hi, g.Wi, g.Ci, g.Co, 1);
+        return direct;
+    }
+    if (!f16 && fast_enabled() && which < 2 && conv_s2k4_wino_ok(g, which)) {
+        if (which == 0) return fused_flops(g.B, g.Ho, g.Wo, g.Ci, g.Co, 1, 4);
+        const double halo = 2.0 * g.B * ((double)g.Hp * g.Wp - (double)g.Hi * g.Wi) * g.Ci * g.Co * 2.0;      // 2 of the 4 taps of a parity class per ring position
+        return fused_flops(g.B, g.Ho, g.Wo, g.Co, g.Ci, 4, 1) + halo;
+    }
+    return direct;
 }
 
 }  // namespace aclgan

@@ -214,6 +214,9 @@ struct aclgan_ctx {
     // outputs written once at their storage width -- what a perfectly fused-per-operator implementation must move
     double alg_bytes = 0.0;
     void count(double bytes) { alg_bytes += bytes; }
+    // matrix-pipe FLOPs the step being built EXECUTES (aclgan_step_executed_flops): every convolution at the cost of the path its launchers
+    // choose (direct / Winograd / sub-pixel / parity phases), dense layers at 2 B in out
+    double exec_flops = 0.0;
     size_t keep_total = 0;      // bytes of Winograd input transforms kept for the weight gradients of this update (conv_block)
     // diagnostics (aclgan_debug_capture_masks): the ReLU / LeakyReLU masks of every Conv2dBlock an update back-propagates through, one byte per
     // element, appended to a caller-owned device buffer in the order the forward builds them (tests/test_gpu_maskfrozen.py)
@@ -763,6 +766,7 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
     if (ubytes && c.ucache_reserve(W.w, g.up ? 2 : 0, ubytes)) { set_error("workspace too small (filter-transform cache)"); return ACLGAN_ENOMEM; }
     const double es_in = in->dt ? 2.0 : 4.0, es_co = co->dt ? 2.0 : 4.0, es_out = out->dt ? 2.0 : 4.0, es_w = f16 ? 2.0 : 4.0;
     c.count(es_in * (double)in->numel() + es_w * (double)Co * g.K + 4.0 * Co + es_co * (double)co->numel());             // conv: x, w, bias -> y
+    c.exec_flops += conv_exec_flops(g, 0, f16);
     if (out != co) c.count((es_co + es_out) * (double)co->numel() + ((has_norm && residual) ? (residual->dt ? 2.0 : 4.0) * (double)co->numel() : 0.0));   // norm+act(+residual) / conversion: y -> out
     const size_t mark = c.top;
     // normalisation statistics from the conv epilogue where the forward kernel offers them (Winograd output transform)
@@ -811,8 +815,8 @@ static int conv_block(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int Co,
         // backward of norm / activation: x (or y), dy -> dx (+ dres); wgrad: x, dy -> dw, db; dgrad: dy, w -> dx
         const double eg_out = out->gdt ? 2.0 : 4.0, eg_co = (has_norm ? co->gdt : (s_bwd ? dt : out->gdt)) ? 2.0 : 4.0, eg_in = gin->gdt ? 2.0 : 4.0;
         c.count((es_co + eg_out + eg_co) * (double)co->numel() + ((residual && residual->need_grad) ? (residual->gdt ? 2.0 : 4.0) * (double)co->numel() : 0.0));
-        if (train_w) c.count(es_in * (double)in->numel() + eg_co * (double)co->numel() + 4.0 * ((double)Co * g.K + Co));
-        if (gin->need_grad) c.count(eg_co * (double)co->numel() + es_w * (double)Co * g.K + eg_in * (double)in->numel());
+        if (train_w) { c.count(es_in * (double)in->numel() + eg_co * (double)co->numel() + 4.0 * ((double)Co * g.K + Co)); c.exec_flops += conv_exec_flops(g, 2, w16); }
+        if (gin->need_grad) { c.count(eg_co * (double)co->numel() + es_w * (double)Co * g.K + eg_in * (double)in->numel()); c.exec_flops += conv_exec_flops(g, 1, d16); }
         const bool side = train_w && aclgan_ctx::side_enabled();      // this layer's weight gradient goes to the side stream
         if (ubytes && gin->need_grad && !d16 && c.ucache_reserve(W.w, g.up ? 3 : 1, ubytes)) { set_error("workspace too small (filter-transform cache)"); return ACLGAN_ENOMEM; }
         float* g16 = nullptr;
@@ -1716,7 +1720,7 @@ int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int 
     memset(&hp, 0, sizeof hp);
     hp.focus_loss = c.arch.gen_output_dim == 4 ? 1.f : 0.f; hp.alpha = 1.f;      // (the branch the architecture can run: gen.output_dim 4 = focus, 3 = non-focus)
     c.reset_step();
-    c.dry = true; c.peak = 0; c.trained = which; c.alg_bytes = 0.0;
+    c.dry = true; c.peak = 0; c.trained = which; c.alg_bytes = 0.0; c.exec_flops = 0.0;
     const aclgan_bucket_fn keep = c.bucket_fn;
     c.bucket_fn = nullptr;
     const int rc = which == 0 ? gen_update_impl(c, nullptr, nullptr, nullptr, B, H, W, hp, nullptr)
@@ -1727,6 +1731,15 @@ int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int 
     c.peak = 0; c.peak2 = 0;
     if (rc) return rc;
     *out = c.alg_bytes + (4.0 + 28.0) * (double)c.groups[which].numel;    // + zero_grad + Adam (p, g, m, v read; p, m, v written)
+    return ACLGAN_OK;
+}
+// the matrix-pipe FLOPs of the same update as the kernels EXECUTE them (conv_exec_flops: the cost of the path every layer's launchers choose
+// at this shape, dtype and switch setting); a dry run, no GPU needed.  Convolutions only (the dense layers of the MLP are 1e-5 of the step).
+int aclgan_step_executed_flops(aclgan_ctx* ctx, int which, int B, int H, int W, double* out) {
+    double bytes = 0.0;
+    const int rc = aclgan_step_algorithmic_bytes(ctx, which, B, H, W, &bytes);
+    if (rc) return rc;
+    *out = ctx->exec_flops;
     return ACLGAN_OK;
 }
 // workspace of ONE forward-only call (aclgan_gen_encode / aclgan_gen_decode / aclgan_dis_forward) at this image shape:

@@ -67,7 +67,7 @@ def male2female_config():
 BASELINE_BATCH = {"male2female": 8, "selfie2anime": 8, "glasses_removal": 4}
 
 
-TRAFFIC_FILE = "profiles/r05_step_traffic.json"
+TRAFFIC_FILES = ("profiles/r06_step_traffic.json", "profiles/r05_step_traffic.json")      # newest first
 
 
 def library_md5():
@@ -81,22 +81,38 @@ def library_md5():
 
 def step_traffic(dtype, S, B, launches_per_step=None):
     """memory-side bytes of ONE step from the committed PMC passes (rocprofv3 --pmc cannot run inside the timed process):
-    profiles/r05_step_traffic.json, written by scripts/step_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    profiles/r06_step_traffic.json (r05 as a fallback), written by scripts/step_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
     runs of scripts/probe_step.py = sum over every kernel of one dis_update + gen_update of 2 x FETCH_SIZE (gfx950 correction,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE.  The entry records the build it was measured on (md5 of libaclgan_hip.so, kernel
     launches per step): when either differs from the library that is running, the figure is reported with stale = True.
     Returns (bytes or None, source, stale, entry)."""
-    try:
-        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
-            ent = json.load(f).get("%s_%d_b%d" % (dtype, S, B))
-        if not ent:
-            return None, None, None, None
-        stale = ent.get("lib_md5") != library_md5()
-        if launches_per_step is not None and ent.get("launches_per_step") is not None:
-            stale = stale or abs(float(ent["launches_per_step"]) - float(launches_per_step)) > 0.5
-        return ent["bytes_per_step"], "%s:%s_%d_b%d" % (TRAFFIC_FILE, dtype, S, B), bool(stale), ent
-    except Exception:   # noqa: BLE001
-        return None, None, None, None
+    for tf in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, tf)) as f:
+                ent = json.load(f).get("%s_%d_b%d" % (dtype, S, B))
+            if not ent or ent.get("bytes_per_step") is None:
+                continue
+            stale = ent.get("lib_md5") != library_md5()
+            if launches_per_step is not None and ent.get("launches_per_step") is not None:
+                stale = stale or abs(float(ent["launches_per_step"]) - float(launches_per_step)) > 0.5
+            return ent["bytes_per_step"], "%s:%s_%d_b%d" % (tf, dtype, S, B), bool(stale), ent
+        except Exception:   # noqa: BLE001
+            continue
+    return None, None, None, None
+
+
+def executed_flops(L, ctx, B, S):
+    """matrix-pipe FLOPs ONE dis_update + gen_update executes at this shape, from the library's own dry run (aclgan_step_executed_flops: every
+    convolution at the cost of the path its launchers choose -- direct, Winograd F(4x4,3x3) in whole tile blocks, sub-pixel phases + ring,
+    parity phases of the stride-2 layers).  Round 6: replaces the closed formula of flops_per_image (kept below as a cross-check), which
+    could not know which layers the cost models send to which kernel."""
+    import ctypes as C
+    tot = 0.0
+    for which in (0, 1):
+        v = C.c_double()
+        L.check(L.lib.aclgan_step_executed_flops(ctx, which, B, S, S, C.byref(v)), "step_executed_flops")
+        tot += v.value
+    return tot
 
 
 RESBLOCK_GMAC_256 = 637.8     # of which the 3x3 ResBlock convs: 120 forward + 72 dgrad + 72 wgrad launches x 2.4159 GMAC
@@ -201,12 +217,14 @@ def dominant_kernel_probe(L, dtype, reps=20):
         ms = timed(lambda: L.check(L.lib.aclgan_conv3x3_winograd_fused(L.ptr(x), L.ptr(Uf), L.ptr(b), L.ptr(y), B, H, H, Cc, Cc, 0, 1, 0, None, st)))
         flop = 2.0 * 36 * T * Cc * Cc
         alg_bytes = 4.0 * (x.numel() + y.numel() + 36 * Cc * Cc)      # x read, y written, U read: what the launch must move
-        pmc = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r05_pmc_wino_fused.json")) as f:
-                pmc = json.load(f)
-        except Exception:   # noqa: BLE001
-            pass
+        pmc, pmc_file = None, None
+        for pf in ("r06_pmc_wino_fused.json", "r05_pmc_wino_fused.json"):      # newest first
+            try:
+                with open(os.path.join(ROOT, "profiles", pf)) as f:
+                    pmc, pmc_file = json.load(f), pf
+                break
+            except Exception:   # noqa: BLE001
+                continue
         out = {"name": "wino_fused_kernel: ResBlock conv 8x64x64x256->256 3x3 reflect-pad, Winograd F(4x4,3x3) input transform + 36 GEMMs [2048 x 256] x [256 x 256] + "
                        "output transform in one launch",
                "ms": round(ms, 4), "flop_per_launch": flop, "achieved": round(flop / ms / 1e9, 2), "unit": "TFLOP/s",
@@ -215,7 +233,7 @@ def dominant_kernel_probe(L, dtype, reps=20):
                "algorithmic_frac": round(flop_direct / ms / 1e9 / PEAK[dtype], 4),
                "algorithmic_bytes": alg_bytes,
                "traffic": None if not pmc else pmc.get("bytes_per_launch"),
-               "traffic_source": None if not pmc else "profiles/r05_pmc_wino_fused.json (2 x FETCH_SIZE + WRITE_SIZE of this launch)",
+               "traffic_source": None if not pmc else "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE of this launch)" % pmc_file,
                "traffic_stale": None if not pmc else bool(pmc.get("lib_md5") != library_md5()),
                "replaces": "round 3: wino_input + 36-slice GEMM launch + wino_output = 157 us and 469 MB of memory-side traffic per convolution"}
         return out
@@ -516,7 +534,7 @@ def main():
                     otr.dis_update(oa, ob, ocfg, z=oz); otr.gen_update(oa, ob, ocfg, z=oz); otr.update_learning_rate()
                 torch.cuda.synchronize()
                 oms = (time.perf_counter() - to0) * 1e3 / n_o
-                _, oexec = flops_per_image(oS, odt)
+                oexec = executed_flops(L, otr._ctx, oB, oS) / 1e12 / oB      # TFLOP per image, the library's own count
                 other_configs.append({"workload": label, "config_file": "configs/%s.yaml" % yaml_name, "dtype": odt, "size": oS, "batch": oB, "steps": n_o, "warmup": 2,
                                       "ms_per_step": round(oms, 3), "images_per_s": round(oB / oms * 1e3, 2),
                                       "frac": round(oexec * oB / (oms / 1e3) / PEAK[odt], 4), "peak_TFLOPs": PEAK[odt],
@@ -532,7 +550,9 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
-        tflop_img, tflop_exec = flops_per_image(S, args.dtype)
+        tflop_img, tflop_formula = flops_per_image(S, args.dtype)
+        flop_model = executed_flops(L, tr._ctx, B, S)      # FLOPs per step (per GPU) as the kernels execute them: the library's dry run
+        tflop_exec = flop_model / 1e12 / B
         step_s = ev_ms / args.steps / 1e3
         ach = tflop_img * B / step_s      # per GPU, from HIP events on the launch stream
         peak = PEAK[args.dtype]
@@ -546,6 +566,9 @@ def main():
             alg_bytes += v.value
         traffic, traffic_src, traffic_stale, traffic_ent = step_traffic(args.dtype, S, B, launches_per_step)
         ex_ach = tflop_exec * B / step_s
+        # ... and the hardware's own count of the same step where a PMC pass of THIS build is committed (scripts/step_mfma_flops.py)
+        flop_counter = None if not traffic_ent else traffic_ent.get("mfma_flop_per_step")
+        flop_counter_stale = None if flop_counter is None else bool(traffic_ent.get("mfma_lib_md5") != library_md5())
         out = {
             "metric": "training images/sec at 256x256 (gen+dis step)" if S == 256 else "training images/sec at %dx%d (gen+dis step)" % (S, S),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -583,7 +606,13 @@ def main():
             # exceed 1 exactly because of those two algebraic reductions.
             "roofline": {"bound": "mfma", "achieved": round(ex_ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ex_ach / peak, 4),
-                         "flop_per_launch": tflop_exec * B * 1e12, "launch": "one dis_update+gen_update step (per GPU)",
+                         "flop_per_launch": flop_model, "launch": "one dis_update+gen_update step (per GPU)",
+                         "flop_source": "aclgan_step_executed_flops (dry run of the scheduler: the path every layer's launchers choose)",
+                         "flop_per_launch_counter": flop_counter, "flop_counter_source": None if flop_counter is None else "rocprofv3 --pmc SQ_INSTS_MFMA x FLOPs per instruction, " + str(traffic_src),
+                         "flop_counter_stale": flop_counter_stale,
+                         "flop_counter_vs_model": None if not flop_counter else round(flop_counter / flop_model, 4),
+                         "flop_mismatch": None if not flop_counter else bool(abs(flop_counter / flop_model - 1.0) > 0.02),
+                         "flop_per_launch_formula_r05": tflop_formula * B * 1e12,
                          "event_ms_per_step": round(ev_ms / args.steps, 3),
                          "algorithmic_flop_per_launch": tflop_img * B * 1e12, "algorithmic_achieved": round(ach, 2),
                          "algorithmic_frac": round(ach / peak, 4),

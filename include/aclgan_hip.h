@@ -215,6 +215,12 @@ int aclgan_forward_workspace_bytes(aclgan_ctx* ctx, int B, int H, int W, size_t*
  * run of the same scheduler; zero_grad (4 B / parameter) and Adam (28 B / parameter, trainer.py:170,293) included.
  * which: 0 gen_update, 1 dis_update. */
 int aclgan_step_algorithmic_bytes(aclgan_ctx* ctx, int which, int B, int H, int W, double* out);
+/* Round 6: the matrix-pipe FLOPs the same update EXECUTES -- every convolution at the cost of the path its launchers choose at this shape,
+ * compute dtype and switch setting (direct implicit GEMM 2 M Cout K; Winograd F(4x4,3x3) 36 multiplies per 4x4 tile instead of 144, counted
+ * in whole tile blocks where the fused kernel runs; the sub-pixel layers as four 3x3 phases + the exact ring; the 4x4 stride-2 layers as four
+ * parity phases where the fused kernel takes them).  bench.py's roofline.flop_per_launch; checked against rocprofv3 --pmc SQ_INSTS_MFMA
+ * (scripts/step_mfma_flops.py, profiles/r06_step_traffic.json).  A dry run of the scheduler: no launches. */
+int aclgan_step_executed_flops(aclgan_ctx* ctx, int which, int B, int H, int W, double* out);
 
 /* ---- the hot path ---- */
 /* aclgan_Trainer.gen_update minus zero_grad/opt.step (trainer.py:92-169): forward of the whole

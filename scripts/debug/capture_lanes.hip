@@ -60,13 +60,14 @@ static int run(int v, hipStreamCaptureMode mode) {
     case 8: {    // the size of a real update: 2400 kernels over the origin, three lanes and a side stream, a cross edge every 8 launches
         //              (CAP_N / CAP_E: number of kernels / launches per cross edge, for the sweep at the end of main)
         const int nk = getenv("CAP_N") ? atoi(getenv("CAP_N")) : 2400, ep = getenv("CAP_E") ? atoi(getenv("CAP_E")) : 8;
-        for (int l = 0; l < 4; ++l) CK(edge(origin, s[l]));
+        const int ns = getenv("CAP_S") ? atoi(getenv("CAP_S")) : 4, nt = ns + 1;      // side streams (the origin is stream index ns)
+        for (int l = 0; l < ns; ++l) CK(edge(origin, s[l]));
         for (int i = 0; i < nk; ++i) {
-            const int l = i % 5; hipStream_t st = l == 4 ? origin : s[l];
+            const int l = i % nt; hipStream_t st = l == ns ? origin : s[l];
             CK(K(st, l));
-            if (i % ep == ep - 1) { const int t = (i / ep) % 5; hipStream_t to = t == 4 ? origin : s[t]; if (to != st) CK(edge(st, to)); }
+            if (i % ep == ep - 1) { const int t = (i / ep) % nt; hipStream_t to = t == ns ? origin : s[t]; if (to != st) CK(edge(st, to)); }
         }
-        for (int l = 0; l < 4; ++l) CK(edge(s[l], origin));
+        for (int l = 0; l < ns; ++l) CK(edge(s[l], origin));
         break; }
     case 9: {    // the join pattern of lanes_join + side_join, then MORE work and a second join (bucket hand-outs in the middle of the backward)
         for (int r = 0; r < 6; ++r) {
@@ -79,9 +80,12 @@ static int run(int v, hipStreamCaptureMode mode) {
     }
     CK(K(origin, 0));
     hipGraph_t g = nullptr;
+    printf("    hipStreamEndCapture ..."); fflush(stdout);
     CK(hipStreamEndCapture(origin, &g));
     hipGraphExec_t ge = nullptr;
+    printf(" hipGraphInstantiate ..."); fflush(stdout);
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    printf(" hipGraphLaunch ...\n"); fflush(stdout);
     for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, origin));
     CK(hipStreamSynchronize(origin));
     size_t nodes = 0; CK(hipGraphGetNodes(g, nullptr, &nodes));
@@ -100,14 +104,15 @@ static void child(int v, hipStreamCaptureMode mode) {
 
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "sweep")) {      // how large / how connected may a multi-stream capture be?
-        const int ns[] = {100, 200, 400, 800, 1200, 1600, 2400}, es[] = {4, 8, 32, 128, 100000};
-        for (int e : es)
-            for (int n : ns) {
-                char a[32], b[32]; snprintf(a, sizeof a, "%d", n); snprintf(b, sizeof b, "%d", e);
-                setenv("CAP_N", a, 1); setenv("CAP_E", b, 1);
-                printf("[sweep] %d kernels over 5 streams, one cross edge per %d launches\n", n, e); fflush(stdout);
-                child(8, hipStreamCaptureModeThreadLocal);
-            }
+        const int ns[] = {100, 400, 2400}, es[] = {4, 8, 32, 128, 100000};
+        for (int st = 1; st <= 4; ++st)
+            for (int e : es)
+                for (int n : ns) {
+                    char a[32], b[32], c[32]; snprintf(a, sizeof a, "%d", n); snprintf(b, sizeof b, "%d", e); snprintf(c, sizeof c, "%d", st);
+                    setenv("CAP_N", a, 1); setenv("CAP_E", b, 1); setenv("CAP_S", c, 1);
+                    printf("[sweep] %d kernels over the origin + %d streams, one cross edge per %d launches\n", n, st, e); fflush(stdout);
+                    child(8, hipStreamCaptureModeThreadLocal);
+                }
         return 0;
     }
     const char* names[] = {"", "fork/join 3 lanes", "wait-only lane, rejoined", "wait-only lane, NOT rejoined (expect an error code)", "memset on the origin before the fork",
