@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/r06${TAG:+_$TAG}
 mkdir -p $O
 export TMPDIR=/tmp
-STAGES=${STAGES:-"tests smoke bench trace trace_lanes1 trace16 traffic traffic16 pmcfused pmc16 roctx"}
+STAGES=${STAGES:-"tests smoke bench trace trace_ss0 trace16 trace16_ss0 traffic traffic16 traffic16f traffic512 pmcfused capture"}
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 B="python bench.py --no-cpu-baseline"
 summ() { python - "$1" <<'PY'
@@ -53,6 +53,8 @@ if has trace; then trace 256_fp32 ""; fi
 if has trace_ss0; then ACLGAN_SIDE_STREAM=0 trace 256_fp32_side_stream_off ""; fi
 if has trace_lanes1; then trace 256_fp32_lanes1 "--lanes 1"; fi      # one queue: kernel times without co-residency effects
 if has trace16; then trace 256_bf16 "--dtype bf16"; fi
+if has trace16_ss0; then ACLGAN_SIDE_STREAM=0 trace 256_bf16_side_stream_off "--dtype bf16"; fi      # one queue: the bf16 family table
+if has trace16f_ss0; then ACLGAN_SIDE_STREAM=0 trace 256_fp16_b32_side_stream_off "--dtype fp16"; fi
 if has trace512; then trace 512_fp32 "--config configs/glasses_removal.yaml"; fi
 traffic() {   # dtype size batch
     export PROBE_STEP_JSON=$O/probe_step_$1_$2_b$3.json
@@ -117,4 +119,9 @@ if has roctx; then
     head -50 $O/kernel_time_by_pass.txt | cut -c 1-150 | tee -a $O/progress.log
 fi
 if [ -n "${EXTRA:-}" ]; then echo "== extra: $EXTRA" | tee -a $O/progress.log; (eval "$EXTRA") 2>&1 | tail -${EXTRA_TAIL:-40} | tee -a $O/progress.log; fi
+if has capture; then      # round 6: minimal reproduction of the multi-stream capture crash (scripts/debug/capture_lanes.hip)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/capture_lanes scripts/debug/capture_lanes.hip > $O/capture_build.log 2>&1
+    timeout 300 /tmp/capture_lanes > $O/capture_variants.txt 2>&1; paste - - < $O/capture_variants.txt | cut -c 1-160 | tee -a $O/progress.log
+    timeout 900 /tmp/capture_lanes sweep > $O/capture_sweep.txt 2>&1; paste - - < $O/capture_sweep.txt | cut -c 1-170 | tee -a $O/progress.log
+fi
 echo "== done" | tee -a $O/progress.log

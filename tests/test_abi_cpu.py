@@ -112,6 +112,45 @@ def test_product_path_refuses_to_run_without_gpu():
         trainer.arch_from_config(cfg)
 
 
+def test_step_executed_flops_dry_run_without_gpu():
+    """aclgan_step_executed_flops (round 6; bench.py roofline.flop_per_launch): the matrix-pipe FLOPs an update executes, from a dry run of the
+    scheduler with the launchers' own path decisions.  fp32: Winograd / sub-pixel / parity phases execute far fewer FLOPs than the SURVEY 8d
+    contract (2.623 TFLOP per image at 256x256); the 16-bit paths have no Winograd; the count scales with the image area and (beyond the grid
+    quantisation of the fused kernels) with the batch; forcing the direct kernels raises it."""
+    L = _lib()
+    a = L.Arch(3, 6, 64, 256, 8, 4, 2, 4, 64, 4, 3)
+    fake = C.c_void_p(0x10000)
+
+    def total(B, S, dtype=0):
+        ctx = C.c_void_p()
+        L.check(L.lib.aclgan_ctx_create(C.byref(a), C.byref(ctx)))
+        L.check(L.lib.aclgan_set_compute_dtype(ctx, dtype))
+        for grp in (0, 1):
+            L.check(L.lib.aclgan_bind_params(ctx, grp, fake, fake, fake, fake))
+            if dtype:
+                L.check(L.lib.aclgan_bind_params16(ctx, grp, fake, fake))
+        t = 0.0
+        for which in (0, 1):
+            v = C.c_double()
+            L.check(L.lib.aclgan_step_executed_flops(ctx, which, B, S, S, C.byref(v)))
+            t += v.value
+        L.lib.aclgan_ctx_destroy(ctx)
+        return t
+    contract = 2.623e12 * 8
+    f32 = total(8, 256)
+    assert 0.25 * contract < f32 < 0.35 * contract, f32 / contract      # measured by SQ_INSTS_MFMA on the round-6 build: 6.34e12 (profiles/r06_step_traffic.json)
+    assert 5.8e12 < f32 < 6.6e12, f32
+    bf = total(8, 256, 1)
+    assert 0.55 * contract < bf < 0.85 * contract, bf / contract          # sub-pixel phases only: no Winograd on the 16-bit pipes
+    assert abs(total(4, 512) / (2 * f32) - 1.0) < 0.1                     # 4 x the area, half the batch (different tile-block quantisation)
+    old = L.lib.aclgan_set_tuning(b"wino_fused", 0)
+    try:
+        assert total(8, 256) > f32 * 1.03                                  # the stride-2 layers back on the direct kernels: 16 / 9 of their FLOPs
+    finally:
+        L.lib.aclgan_set_tuning(b"wino_fused", old)
+    assert L.lib.aclgan_launch_count() == 0
+
+
 def test_step_algorithmic_bytes_dry_run_without_gpu():
     """aclgan_step_algorithmic_bytes (bench.py roofline.algorithmic_bytes) is a launch-free dry run of the step scheduler: host logic.
     Conv / norm / loss traffic scales with B*H*W exactly; the parameter traffic (weights read per pass, zero_grad, Adam) does not."""
