@@ -274,6 +274,7 @@ int aclgan_tuning(const char* key, int value, int* previous) {
     else if (!strcmp(key, "wino_x3")) old = set_wino_x3(value);
     else if (!strcmp(key, "wino_fused")) old = set_wino_fused(value);
     else if (!strcmp(key, "wino_wgrad_fused")) old = set_wino_wgrad_fused(value);
+    else if (!strcmp(key, "wino_s2k4")) old = set_wino_s2k4(value);
     else if (!strcmp(key, "dgrad16s_direct")) old = set_dgrad16s_direct(value);
     else if (!strcmp(key, "fwd16_patch")) old = set_fwd16_patch(value);
     else if (!strcmp(key, "lanes")) old = set_lanes(value);
@@ -293,6 +294,7 @@ int aclgan_tuning_get(const char* key, long long* value) {
     int old = 0;
     if (!strcmp(key, "wino_fused")) old = wino_fused_mode();
     else if (!strcmp(key, "wino_wgrad_fused")) old = wino_wgrad_fused_mode();
+    else if (!strcmp(key, "wino_s2k4")) old = wino_s2k4_setting();
     else if (!strcmp(key, "lanes")) old = lanes_setting();
     else if (!strcmp(key, "u_batch")) old = u_batch_setting();
     else if (!strcmp(key, "norm_mask")) old = norm_mask_setting();

@@ -199,6 +199,8 @@ int wino_fused_s2k4_fwd(int B, int Hi, int Wi, int Ci, int Co, const float* x, c
 int wino_fused_s2k4_dgrad(int B, int Hi, int Wi, int Ci, int Co, const float* dy, const float* Uf, float* dx, int accumulate, hipStream_t st);
 // ... and their conv-level wrappers (conv_wino.hip): which = 0 forward, 1 input gradient (interior of the padded grid; never in deterministic mode)
 bool conv_s2k4_wino_ok(const ConvGeom& g, int which);
+int wino_s2k4_setting();                        // tuning switch "wino_s2k4": 1 = on (default), 0 = the stride-2 layers keep the direct kernels
+int set_wino_s2k4(int v);
 size_t conv_s2k4_wino_scratch_bytes(const ConvGeom& g);
 int conv_fwd_s2k4_wino(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* scratch, hipStream_t st, float* stats = nullptr);
 int conv_dgrad_s2k4_wino_interior(const ConvGeom& g, const float* dy, const float* w, float* dx, int accumulate, void* scratch, hipStream_t st);

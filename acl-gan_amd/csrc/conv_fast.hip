@@ -1324,6 +1324,11 @@ double conv_exec_flops(const ConvGeom& g, int which, bool f16) {
         const double halo = 2.0 * g.B * ((double)g.Hp * g.Wp - (double)g.Hi * g.Wi) * g.Ci * g.Co * 2.0;      // 2 of the 4 taps of a parity class per ring position
         return fused_flops(g.B, g.Ho, g.Wo, g.Co, g.Ci, 4, 1) + halo;
     }
+    // direct kernels: whole tiles along the narrow dimension.  The input gradient of an image-side layer (Cin 3 / 6: the first discriminator
+    // layers) runs on 32-column tiles -- 32 / Cin times the necessary FLOPs; the thin-channel weight gradients (conv_small.hip, 4x4x1 MFMA
+    // blocks of 4 thin channels, 7 filter rows per workgroup) measured 1.09 x (Cout 4) and 1.09 x 4 / 3 (Cin 3) of theirs (SQ_INSTS_MFMA, round 6)
+    if (which == 1 && g.Ci < 32) return direct * 32.0 / g.Ci;
+    if (which == 2 && g.k == 7 && (g.Ci < 16 || g.Co < 16)) return direct * 1.09 * (g.Ci == 3 ? 4.0 / 3.0 : 1.0);
     return direct;
 }
 

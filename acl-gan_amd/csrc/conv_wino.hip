@@ -18,6 +18,7 @@
 // keeps its small direct launch, conv_fast.hip mode 2).  The weight gradient stays on the direct kernel.
 #include "common.h"
 #include "st16.h"
+#include <atomic>
 #include <cstdlib>
 #include <algorithm>
 
@@ -843,10 +844,16 @@ int conv_up5_wino_wgrad_phases(const ConvGeom& g, const float* x, const float* d
 // grid phases writing the parity views of dx); the mirrored halo ring keeps the direct kernel's small launch.  ACLGAN_NOWINOS2=1 keeps the
 // direct kernels; the per-shape decision is wino_fused_s2k4_ok's cost model (aclgan_tuning("wino_fused", 2) takes every eligible shape).
 // ------------------------------------------------------------------------------------------
+// tuning switch "wino_s2k4" (aclgan_tuning; ACLGAN_NOWINOS2=1 sets the default to 0): 0 = the stride-2 layers stay on the direct kernels
+static std::atomic<int> g_wino_s2k4{-1};
+int wino_s2k4_setting() {
+    int v = g_wino_s2k4.load();
+    if (v < 0) { const char* e = getenv("ACLGAN_NOWINOS2"); v = (e && atoi(e)) ? 0 : 1; g_wino_s2k4.store(v); }
+    return v;
+}
+int set_wino_s2k4(int v) { const int old = wino_s2k4_setting(); g_wino_s2k4.store(v ? 1 : 0); return old; }
 bool conv_s2k4_wino_ok(const ConvGeom& g, int which) {
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("ACLGAN_NOWINOS2"); off = (e && atoi(e)) ? 1 : 0; }
-    if (off || !wino_enabled() || g.k != 4 || g.s != 2 || g.p != 1 || g.up != 0) return false;
+    if (!wino_s2k4_setting() || !wino_enabled() || g.k != 4 || g.s != 2 || g.p != 1 || g.up != 0) return false;
     if (which == 1 && deterministic()) return false;      // (the ordered ring fold of that mode is wired for the 3x3 layers only)
     return wino_fused_s2k4_ok(g.B, g.Hi, g.Wi, g.Ci, g.Co, which ? ACLGAN_ACT_NONE : g.act, which);
 }

@@ -951,6 +951,24 @@ static int prefill_wino_u(aclgan_ctx& c, int net, int B, int H, int W, bool trai
     return ACLGAN_OK;
 }
 
+// Round 6: the batched transforms of an update (8 launches of ~60 us in gen_update, 4 in dis_update: 19 MB of output each) used to sit in the
+// preamble on lane 0, in front of the chain everything else waits for, although the first layer that reads one is the fourth of the first
+// encoder pass.  They now run on the last lane beside the first three encoder layers; the cache entries carry that lane's stamp, so a reader
+// on another lane waits for exactly the launch that fills its entry (ucache_lookup).  The lane first waits for lane 0's checkpoint: the
+// previous call's optimizer step wrote the parameters on the caller's stream.
+static int prefill_on_side_lane(aclgan_ctx& c, int B, int H, int W, bool train) {
+    const int AB = ACLGAN_NET_GEN_AB, BA = ACLGAN_NET_GEN_BA;
+    if (c.nlanes <= 1) { CHK(prefill_wino_u(c, AB, B, H, W, train)); return prefill_wino_u(c, BA, B, H, W, train); }
+    const int LP = c.nlanes - 1;
+    CHK(c.mark());
+    const int k0 = c.nck(0) - 1;
+    CHK(c.set_lane(LP));
+    CHK(c.wait_ck(LP, 0, k0));
+    CHK(prefill_wino_u(c, AB, B, H, W, train)); CHK(prefill_wino_u(c, BA, B, H, W, train));
+    CHK(c.mark());
+    return c.set_lane(0);
+}
+
 // ContentEncoder.forward (networks.py:230-245)
 static int content_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out) {
     PassScope pass(c, net, "encode");
@@ -1399,7 +1417,7 @@ static int gen_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     CHK(wrap_vec(c, z + (size_t)2 * B * sd, B, sd, 1.f, &z3));
     // the Winograd transforms of all ResBlock filters this update will use: one batched launch per (network, encoder | decoder,
     // forward | input gradient) instead of one per filter and use
-    CHK(prefill_wino_u(c, AB, B, H, W, true)); CHK(prefill_wino_u(c, BA, B, H, W, true));
+    CHK(prefill_on_side_lane(c, B, H, W, true));
     Act *c1, *c2, *s2, *c4, *s4, *c3;
     Act *dB4, *dA4, *xB, *xA, *pA1, *rA4, *rB4, *dA24, *xA2, *pA2;
     // joint discriminator inputs: (x_A_fake | x_A2_fake) for dis_A, (pair_A1 | pair_A2) for dis_2
@@ -1524,7 +1542,7 @@ static int dis_update_impl(aclgan_ctx& c, const float* x_a, const float* x_b, co
     CHK(wrap_vec(c, z, B, sd, 1.f, &z1));
     CHK(wrap_vec(c, z + (size_t)B * sd, B, sd, hp.alpha, &z2));
     CHK(wrap_vec(c, z + (size_t)2 * B * sd, B, sd, 1.f, &z3));
-    CHK(prefill_wino_u(c, AB, B, H, W, false)); CHK(prefill_wino_u(c, BA, B, H, W, false));
+    CHK(prefill_on_side_lane(c, B, H, W, false));
     Act *c1, *c2, *c3, *dB4, *dA4, *dA24, *xB, *xA, *xA2, *pA1, *pA2;
     // joint discriminator inputs: dis_A sees (x_A_fake | x_A2_fake | x_a), dis_B (x_B_fake | x_b), dis_2 (pair_A1 | pair_A2)
     Act* jA = c.new_act(3 * B, H, W, 3, false);

@@ -342,10 +342,13 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
  * key "wino_wgrad_fused" (round 4): 0 = their weight gradient runs as the seven-launch pipeline of csrc/conv_wino.hip, 1 (default) / 2 = as the
  * one-kernel Winograd weight gradient (csrc/conv_wino_wgrad_fused.hip) wherever the shape is eligible (W a multiple of 16, H of 4, Cout of 64,
  * Cin of 32).
+ * key "wino_s2k4" (round 6): 1 (default) = the 4x4 stride-2 reflect-pad-1 layers (networks.py:41, 216-221, 236-241) run as four parity phases
+ * of the same one-launch Winograd kernel wherever "wino_fused" sends them there (1: a cost model per shape, 2: every eligible shape) --
+ * forward and the interior of the input gradient; 0 = they keep the direct implicit-GEMM kernels (ACLGAN_NOWINOS2=1).
  * key "fwd16_patch" (round 5): 1 (default) = the 3x3 stride-1 layers on 32- / 64-pixel-wide maps (the ResBlock convolutions) take
  * conv_fwd16p_kernel (csrc/conv_glds16.hip: the reflect-padded input patch of a 256-pixel tile stays in LDS for all nine taps; 2 = its
  * counter-phase schedule, a measured alternative), 0 = conv_fwd16s.
- * key "lanes" (round 5): 1 .. 4 HIP streams the independent branches of an update are spread over (the two translation directions,
+ * key "lanes" (round 5): 1 .. 3 HIP streams the independent branches of an update are spread over (the two translation directions,
  * the reconstruction decodes, the discriminators and their scales: reference trainer.py:103-139, 258-286; csrc/engine.hip "Lanes");
  * 1 = one queue (the round-4 plan), default 3 (ACLGAN_LANES).  Results do not depend on it.  key "u_batch" (round 5): 1 (default) =
  * the Winograd transforms of all ResBlock filters of a network are one launch at the start of an update, 0 = one launch per filter at
@@ -359,7 +362,7 @@ int aclgan_set_tuning(const char* key, int value);
  * ACLGAN_EINVAL for an unknown key (aclgan_set_tuning cannot tell -1 "unknown" from a previous value). */
 int aclgan_tuning(const char* key, int value, int* previous);
 /* Read a switch without touching it (round 6; no state change, no tuning-epoch bump): keys "lanes", "u_batch", "norm_mask", "wino_fused",
- * "wino_wgrad_fused", "fault_at", and "epoch" = the number of aclgan_tuning calls so far (cached switch-dependent results -- an arena
+ * "wino_wgrad_fused", "wino_s2k4", "fault_at", and "epoch" = the number of aclgan_tuning calls so far (cached switch-dependent results -- an arena
  * size -- are valid for one epoch).  ACLGAN_EINVAL for any other key. */
 int aclgan_tuning_get(const char* key, long long* value);
 /* The same launch with the normalisation statistics taken from its epilogue (round 3; replaces the norm_stats pass over y that

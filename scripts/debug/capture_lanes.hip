@@ -76,6 +76,25 @@ static int run(int v, hipStreamCaptureMode mode) {
             CK(K(origin, 0));
         }
         break; }
+    case 10: {   // CAP_S side streams exchanging events in a RING (s0 -> s1 -> ... -> s0), CAP_N rounds: the smallest pattern of the sweep's failures
+        const int ns = getenv("CAP_S") ? atoi(getenv("CAP_S")) : 3, rounds = getenv("CAP_N") ? atoi(getenv("CAP_N")) : 1;
+        for (int l = 0; l < ns; ++l) { CK(edge(origin, s[l])); CK(K(s[l], l + 1)); }
+        for (int r = 0; r < rounds; ++r)
+            for (int l = 0; l < ns; ++l) { CK(edge(s[l], s[(l + 1) % ns])); CK(K(s[(l + 1) % ns], (l + 1) % ns + 1)); }
+        for (int l = 0; l < ns; ++l) CK(edge(s[l], origin));
+        break; }
+    case 11: {   // random cross edges among the origin and CAP_S side streams (seed CAP_E), CAP_N kernels, one edge per 6 launches
+        const int ns = getenv("CAP_S") ? atoi(getenv("CAP_S")) : 3, nk = getenv("CAP_N") ? atoi(getenv("CAP_N")) : 600;
+        unsigned int rng = 12345u + (getenv("CAP_E") ? atoi(getenv("CAP_E")) : 0) * 7919u;
+        auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return (rng >> 10); };
+        for (int l = 0; l < ns; ++l) CK(edge(origin, s[l]));
+        for (int i = 0; i < nk; ++i) {
+            const int l = rnd() % (ns + 1); hipStream_t st = l == ns ? origin : s[l];
+            CK(K(st, l));
+            if (i % 6 == 5) { const int a = rnd() % (ns + 1), b = rnd() % (ns + 1); if (a != b) CK(edge(a == ns ? origin : s[a], b == ns ? origin : s[b])); }
+        }
+        for (int l = 0; l < ns; ++l) CK(edge(s[l], origin));
+        break; }
     default: break;
     }
     CK(K(origin, 0));
@@ -103,6 +122,23 @@ static void child(int v, hipStreamCaptureMode mode) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "rings")) {      // which ring sizes / round counts / random patterns survive hipStreamEndCapture?
+        for (int st = 2; st <= 4; ++st)
+            for (int rounds : {1, 2, 8, 64}) {
+                char a[32], c[32]; snprintf(a, sizeof a, "%d", rounds); snprintf(c, sizeof c, "%d", st);
+                setenv("CAP_N", a, 1); setenv("CAP_S", c, 1);
+                printf("[ring] %d side streams, %d rounds\n", st, rounds); fflush(stdout);
+                child(10, hipStreamCaptureModeThreadLocal);
+            }
+        for (int st = 2; st <= 4; ++st)
+            for (int seed = 0; seed < 4; ++seed) {
+                char b[32], c[32]; snprintf(b, sizeof b, "%d", seed); snprintf(c, sizeof c, "%d", st);
+                setenv("CAP_N", "600", 1); setenv("CAP_E", b, 1); setenv("CAP_S", c, 1);
+                printf("[random] origin + %d side streams, 600 kernels, 100 random cross edges, seed %d\n", st, seed); fflush(stdout);
+                child(11, hipStreamCaptureModeThreadLocal);
+            }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "sweep")) {      // how large / how connected may a multi-stream capture be?
         const int ns[] = {100, 400, 2400}, es[] = {4, 8, 32, 128, 100000};
         for (int st = 1; st <= 4; ++st)

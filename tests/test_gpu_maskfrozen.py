@@ -110,7 +110,19 @@ def _grad_errors(tr, orc, nets_, scale=1.0, floor=1e-3):
     return out
 
 
-def _frozen_and_free(T, dt, B, S, seed):
+def _frozen_and_free(T, dt, B, S, seed, forced=False):
+    """forced: every eligible convolution through the one-launch Winograd kernel (tuning wino_fused = 2): at B = 2 the cost models keep the
+    4x4 stride-2 layers and the small grids on the direct kernels / the pipeline, so the default run does not reach those kernels"""
+    from aclgan_amd import _lib as L
+    old = L.lib.aclgan_set_tuning(b"wino_fused", 2) if forced else None
+    try:
+        return _frozen_and_free_impl(T, dt, B, S, seed)
+    finally:
+        if forced:
+            L.lib.aclgan_set_tuning(b"wino_fused", old)
+
+
+def _frozen_and_free_impl(T, dt, B, S, seed):
     cfg = O.default_config()
     cfg["display_size"] = 1
     cfg["focus_epsilon"] = 0.5      # smooth fixture (tests/golden/make_golden.py: the default 0.01 has a sign discontinuity of 1e4 at m = 0.5)
@@ -162,10 +174,13 @@ def _per_net(errs):
     return out
 
 
-def test_backward_parity_with_frozen_masks_fp32(T):
+@pytest.mark.parametrize("forced", [False, True], ids=["default-paths", "fused-winograd-forced"])
+def test_backward_parity_with_frozen_masks_fp32(T, forced):
     """256x256 B=2, full width: with the HIP update's own ReLU / LeakyReLU masks replayed by the oracle every gradient tensor agrees to 1e-3
-    relative L2 (the bound of tests/test_gpu_fullsize.py on the un-frozen comparison stays 1e-2)."""
-    res = _frozen_and_free(T, None, 2, 256, 31)
+    relative L2 (the bound of tests/test_gpu_fullsize.py on the un-frozen comparison stays 1e-2).  Second case: the one-launch Winograd kernel
+    FORCED on every eligible layer -- the 3x3 ResBlock layers, the sub-pixel phases and (round 6) the four parity phases of the 4x4 stride-2
+    layers, forward and input gradient -- the kernels the benchmarked batch runs but B = 2 would not reach."""
+    res = _frozen_and_free(T, None, 2, 256, 31, forced=forced)
     for which in ("dis", "gen"):
         r = res[which]
         # every activation a gradient passes through was matched (dis_update: the generator pass is forward-only in the HIP update)
