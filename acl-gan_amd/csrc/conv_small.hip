@@ -484,13 +484,135 @@ bool small_enabled() {
 
 }  // namespace
 
+// ---------------- round 6: thin (CS = 3 / 4 / 6 channels) -> 64 channels, K x K / stride S / reflect pad P, pipelined ----------------
+// conv_thin_in_kernel's GEMM scheme (patch in LDS, every A fragment a ds_read_b32 at pixel_base + const(k)) generalised to the first
+// discriminator layers (4x4 stride 2 pad 1, Cin 3 / 6: networks.py:41 -- they ran on the general implicit-GEMM kernel with scalar gathers,
+// 59 - 87 us for 67 MB of output) and restructured around what the PMC pass of the 7x7 kernel showed (profiles/r06_experiments.md section 5:
+// MFMA pipe 45 % busy, 4.5 VALU instructions per MFMA of which 4 in the staging loops and the store epilogue, waves parked 42 % of the time --
+// every workgroup of a CU in its load phase at once):
+//   * a workgroup walks `tpw` vertically adjacent tiles with the weights staged ONCE, and fetches the patch of tile t + 1 into registers
+//     before the K loop of tile t (the global latency hides behind the MFMAs; LDS holds one patch);
+//   * the staging loops carry no integer division by a runtime value (rows per wave, lanes along the contiguous (x, c) run);
+//   * the epilogue stores through one row pointer per output row with compile-time column offsets.
+// Lane stride of the A reads is S * CS floats (stride 2, 6 channels: a 4-way bank conflict on 4 reads per 256 MFMA cycles: irrelevant).
+template <int CS, int K, int S, int P>
+__global__ void __launch_bounds__(256, 2) conv_thin_in2_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int H, int W, int Ho, int Wo, int act, int tiles_x, int tiles_y, int tpw) {
+    constexpr int PH = S * (TH - 1) + K, PW = S * (TW - 1) + K, ROWE = PW * CS;      // patch rows / columns, floats per patch row
+    constexpr int KT = K * K * CS, KS = (KT + 1) / 2, LDW = 65, ROWJ = (PW - K) * CS;
+    constexpr int NE = PH * ROWE, NPR = (NE + 255) / 256;                              // patch elements, per thread
+    constexpr bool PF = NPR <= 16;      // prefetch the next patch under the K loop (6 channels at stride 2: 28 registers per thread -- spills; its K loop is short)
+    __shared__ float patch[NE + ROWE];                   // + one zero row: the odd-K pad element reads it
+    __shared__ float wl[2 * KS * LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    // weights -> LDS [k][co]: wave w stages couts 16 w .. 16 w + 15, its lanes walk k (coalesced along OHWI's (tap, c)); zero row for the K pad
+    for (int cc = 0; cc < 16; ++cc) {
+        const int co = wave * 16 + cc;
+        for (int k = lane; k < 2 * KS; k += 64) wl[k * LDW + co] = k < KT ? w[(size_t)co * KT + k] : 0.f;
+    }
+    for (int i = tid; i < ROWE; i += 256) patch[NE + i] = 0.f;
+    const int ngy = (tiles_y + tpw - 1) / tpw;
+    const int gyi = blockIdx.x % ngy, rest = blockIdx.x / ngy, txi = rest % tiles_x, b = rest / tiles_x;
+    const int tx0 = txi * TW;
+    const float* inb = in + (size_t)b * H * W * CS;
+    float pv[NPR];
+    auto fetch = [&](int tyi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            const int e = tid + 256 * j;
+            if (NE % 256 == 0 || e < NE) {
+                const int py = e / ROWE, r = e - py * ROWE, px = r / CS, c = r - px * CS;          // (constant divisors)
+                // clamp after reflecting: halo pixels of tiles that overhang the image feed only outputs that are never stored
+                const int iy = min(max(refl(S * tyi * TH + py - P, H), 0), H - 1), ix = min(max(refl(S * tx0 + px - P, W), 0), W - 1);
+                pv[j] = inb[((size_t)iy * W + ix) * CS + c];
+            }
+        }
+    };
+    int tyi = gyi * tpw;
+    if (PF && tyi < tiles_y) fetch(tyi);
+    const float* pN = patch + S * ((2 * wave) * PW + l31) * CS + kh;              // lane half kh reads k + kh: + 1 float ...
+    const float* pX = patch + S * ((2 * wave) * PW + l31) * CS + kh * (1 + ROWJ);  // ... or + 1 plus the row jump when k + 1 opens a filter row
+    const float* pb = wl + kh * LDW + l31;
+    const float bv0 = bias ? bias[l31] : 0.f, bv1 = bias ? bias[l31 + 32] : 0.f;
+    for (int tt = 0; tt < tpw && tyi < tiles_y; ++tt, ++tyi) {
+        if (!PF) fetch(tyi);
+        __syncthreads();                                  // the previous tile's K loop has read the patch (first pass: the weights are staged)
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            const int e = tid + 256 * j;
+            if (NE % 256 == 0 || e < NE) patch[e] = pv[j];
+        }
+        __syncthreads();
+        if (PF && tt + 1 < tpw && tyi + 1 < tiles_y) fetch(tyi + 1);      // in flight under the K loop
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k0 = 2 * s;
+            const int off0 = k0 + (k0 / (K * CS)) * ROWJ;                        // compile-time after unrolling
+            const bool jump = ((k0 + 1) % (K * CS)) == 0;
+            const float* pa = jump ? pX : pN;
+            const float a0 = pa[off0], a1 = pa[off0 + S * PW * CS];
+            const float b0 = pb[k0 * LDW], b1 = pb[k0 * LDW + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        const int wlim = Wo - tx0 - 4 * kh;               // columns this lane half may store
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = tyi * TH + 2 * wave + i;
+            if (oy >= Ho) continue;                       // (wave-uniform)
+            float* orow = out + ((size_t)(b * Ho + oy) * Wo + tx0 + 4 * kh) * 64 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oxl = (r & 3) + 8 * (r >> 2);
+                if (oxl < wlim) {
+                    orow[oxl * 64] = act_apply(acc[i][0][r] + bv0, act);
+                    orow[oxl * 64 + 32] = act_apply(acc[i][1][r] + bv1, act);
+                }
+            }
+        }
+    }
+}
+
 static bool thin_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("ACLGAN_NOTHIN"); v = (e && atoi(e)) ? 0 : 1; }
     return v == 1;
 }
 
+// tiles per workgroup of conv_thin_in2_kernel: the most that still leaves two workgroups per CU
+static int thin_in2_tpw(int B, int tx, int ty) {
+    for (int t = 4; t > 1; t >>= 1)
+        if ((long long)B * tx * cdiv(ty, t) >= 512) return t;
+    return 1;
+}
+template <int CS, int K, int S, int P>
+static int launch_thin_in2(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+    const int tx = cdiv(g.Wo, TW), ty = cdiv(g.Ho, TH), tpw = thin_in2_tpw(g.B, tx, ty);
+    hipLaunchKernelGGL((conv_thin_in2_kernel<CS, K, S, P>), dim3(g.B * tx * cdiv(ty, tpw)), dim3(256), 0, st, x, w, bias, y, g.Hi, g.Wi, g.Ho, g.Wo, g.act, tx, ty, tpw);
+    ACL_CHECK_LAUNCH("conv_thin_in2_kernel");
+    return ACLGAN_OK;
+}
+// ACLGAN_THININ2=0: the round-2 kernel for the 7x7 layers, the general kernels for the first discriminator layers (A/B switch)
+static bool thin_in2_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_THININ2"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v == 1;
+}
 int conv_fwd_small(const ConvGeom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+    // round 6: the first discriminator layers (4x4 stride 2 reflect pad 1, Cin 3 / 6 -> 64: networks.py:41)
+    if (small_enabled() && thin_enabled() && thin_in2_enabled() && !g.up && g.k == 4 && g.s == 2 && g.p == 1 && g.Co == 64 && (g.Ci == 3 || g.Ci == 6) &&
+        g.Hi >= 2 && g.Wi >= 2)
+        return g.Ci == 3 ? launch_thin_in2<3, 4, 2, 1>(g, x, w, bias, y, st) : launch_thin_in2<6, 4, 2, 1>(g, x, w, bias, y, st);
     if (!small_enabled() || g.s != 1 || g.up || g.k != 7 || g.p != 3 || g.Hu < g.k || g.Wu < g.k) return ACLGAN_EUNSUPPORTED;
     if (thin_enabled() && g.Co <= 4 && g.Ci % 8 == 0) {
         const int tx = cdiv(g.Wi, TW), ty = cdiv(g.Hi, TH);
@@ -498,6 +620,8 @@ int conv_fwd_small(const ConvGeom& g, const float* x, const float* w, const floa
         ACL_CHECK_LAUNCH("conv_thin_out_kernel<fwd>");
         return ACLGAN_OK;
     }
+    if (thin_enabled() && thin_in2_enabled() && g.Co == 64 && (g.Ci == 3 || g.Ci == 4))
+        return g.Ci == 3 ? launch_thin_in2<3, 7, 1, 3>(g, x, w, bias, y, st) : launch_thin_in2<4, 7, 1, 3>(g, x, w, bias, y, st);
     if (thin_enabled() && g.Co == 64 && (g.Ci == 3 || g.Ci == 4)) {
         const int tx = cdiv(g.Wi, TW), ty = cdiv(g.Hi, TH);
         const dim3 grid(g.B * tx * ((ty + 1) / 2));
