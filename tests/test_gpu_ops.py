@@ -46,6 +46,11 @@ CONV_CASES = [
     (3, 12, 20, 16, 8, 4, 2, 1, 0, "lrelu"),     # ragged sizes
     (1, 2, 2, 16, 16, 4, 2, 1, 0, "lrelu"),      # smallest map the 3rd D scale reaches (64x64 input)
     (5, 9, 7, 12, 20, 3, 1, 1, 0, "none"),       # nothing a multiple of anything
+    (3, 12, 20, 3, 64, 4, 2, 1, 0, "lrelu"),     # round 6: D first layer on a ragged map (thin-input kernels: 6 x 10 outputs, 7 x 11 class grid)
+    (2, 66, 40, 6, 64, 4, 2, 1, 0, "lrelu"),     # ... 6-channel pair input, more than one tile in both directions, two tiles per workgroup
+    (1, 128, 96, 3, 64, 4, 2, 1, 0, "none"),     # ... several tiles per workgroup (64 x 48 outputs)
+    (2, 16, 16, 3, 16, 4, 2, 1, 0, "lrelu"),     # ... reduced width (Cout 16: forward on the general kernel, input gradient on the thin one)
+    (2, 40, 72, 3, 64, 7, 1, 3, 0, "relu"),      # CE0 on a map of 5 x 3 tiles (pipelined tiles: 4 / 2 / 1 per workgroup by grid size)
 ]
 
 
