@@ -487,67 +487,63 @@ bool small_enabled() {
 // ---------------- round 6: input gradient of the first discriminator layers (4x4 stride 2 pad 1, Cin 3 / 6 <- Cout 64; networks.py:41) ----------------
 // onto the PADDED grid dxp [B][H+2][W+2][CN] (the reflection fold follows, as after the general kernel, which ran these layers on 32-column
 // tiles: 32 / Cin times the necessary FLOPs, 300 us for 1.6 GFLOP).  A stride-2 transposed convolution splits by the parity (cy, cx) of the
-// padded position into four 2x2-tap stride-1 correlations of dy:  dxp[2m + cy][2n + cx] = sum_{a, b in {0,1}} w[.][cy + 2a][cx + 2b][.] dy[m - a][n - b]
-// -- conv_thin_out_kernel's scheme (v_mfma_f32_4x4x1: lane = pixel of an 8x32 tile of the CLASS grid as A, lane & 3 = thin channel as B) with
-// 4 taps; blockIdx.y = parity class, blockIdx.z = group of 4 thin channels (the 6-channel pair input of dis_2 takes two).
-__global__ void __launch_bounds__(256) conv_thin_s2dg_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dxp,
-                                                             int Ho, int Wo, int Cw, int CN, int Hp, int Wp, int tiles_x, int tiles_y) {
-    constexpr int PH = TH + 1, PW = TW + 1, PS = 12, CH = 8;
-    __shared__ __attribute__((aligned(16))) float patch[PH * PW * PS];
-    __shared__ __attribute__((aligned(16))) float wts[4 * 4 * CH];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / (tiles_x * tiles_y), t = blockIdx.x % (tiles_x * tiles_y);
-    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
-    const int cy = blockIdx.y >> 1, cx = blockIdx.y & 1, n0 = 4 * blockIdx.z;
-    const int Hc = (Hp - cy + 1) >> 1, Wc = (Wp - cx + 1) >> 1;       // positions of this parity class
-    if (ty0 >= Hc || tx0 >= Wc) return;                               // (block-uniform: the classes differ by one row / column)
-    const int ly = 2 * wave + (lane >> 5), lx = lane & 31;
-    f32x4 acc[4];
+// padded position into four 2x2-tap correlations of dy:  dxp[2m + cy][2n + cx] = sum_{a, b in {0,1}} w[.][cy + 2a][cx + 2b][.] dy[m - a][n - b]
+// -- all four classes of a class-grid position (m, n) read the SAME 2x2 neighbourhood of dy, and each of the 16 filter taps is used by exactly
+// one (class, a, b).  So: one thread per (m, n), the neighbourhood loaded once (float4 per 4 channels), 16 x CN accumulators, the weights as
+// wave-uniform scalars (CN <= 6: 96 per output channel) -- a direct VALU kernel as conv_fwd_co4_kernel above, VALU-bound at 3072 / 6144 FMAs per
+// thread (22 / 44 us at 256x256 B=16).  (An MFMA version in the scheme of conv_thin_out_kernel, 4 taps per staged 8-channel chunk, measured
+// 145 / 330 us: all staging.)
+template <int CN>
+__global__ void __launch_bounds__(256) conv_s2k4_thin_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dxp,
+                                                                   int B, int Ho, int Wo, int Co, int Hp, int Wp) {
+    const int Hc = (Hp + 1) >> 1, Wc = (Wp + 1) >> 1;      // class-grid extent (the largest parity class)
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * Hc * Wc) return;
+    const int n = (int)(idx % Wc), m = (int)((idx / Wc) % Hc), b = (int)(idx / ((int64_t)Wc * Hc));
+    float acc[4][CN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < Cw; c0 += CH) {
-        __syncthreads();
-        for (int i = tid; i < PH * PW * 2; i += 256) {
-            const int pix = i >> 1, q = i & 1;
-            const int py = pix / PW, px = pix - py * PW;
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < Ho && gx >= 0 && gx < Wo) v = *reinterpret_cast<const f32x4*>(dy + ((size_t)(b * Ho + gy) * Wo + gx) * Cw + c0 + q * 4);
-            *reinterpret_cast<f32x4*>(patch + pix * PS + q * 4) = v;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < CN; ++i) acc[c][i] = 0.f;
+    // neighbourhood pointers (a, b) -> dy[m - a][n - b]; out-of-range taps read zero
+    const float* nb[2][2]; bool ok[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int y = m - a, x = n - bb;
+            ok[a][bb] = y >= 0 && y < Ho && x >= 0 && x < Wo;
+            nb[a][bb] = dy + ((size_t)(b * Ho + (ok[a][bb] ? y : 0)) * Wo + (ok[a][bb] ? x : 0)) * Co;
         }
-        if (tid < 4 * 4 * 2) {
-            const int q = tid & 1, n = (tid >> 1) & 3, tap = tid >> 3;      // tap = 2 a + b_
-            const int ky = cy + 2 * (tap >> 1), kx = cx + 2 * (tap & 1);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n0 + n < CN) {
+    for (int c0 = 0; c0 < Co; c0 += 4) {
+        f32x4 d[2][2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = w[((size_t)((c0 + q * 4 + e) * 4 + ky) * 4 + kx) * CN + n0 + n];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                d[a][bb] = *reinterpret_cast<const f32x4*>(nb[a][bb] + c0);
+                if (!ok[a][bb]) d[a][bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            *reinterpret_cast<f32x4*>(wts + (tap * 4 + n) * CH + q * 4) = v;
-        }
-        __syncthreads();
-        const float* pb = wts + (lane & 3) * CH;
 #pragma unroll
-        for (int tap = 0; tap < 4; ++tap) {
-            const float* pa = patch + ((ly + 1 - (tap >> 1)) * PW + lx + 1 - (tap & 1)) * PS;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(pa + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb + tap * 4 * CH);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(pb + tap * 4 * CH + 4);
+        for (int e = 0; e < 4; ++e) {
+            const float* wc = w + (size_t)(c0 + e) * 16 * CN;      // wave-uniform: scalar loads
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], acc[e], 0, 0, 0);
+            for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[e], b1[e], acc[e], 0, 0, 0);
+                for (int kx = 0; kx < 4; ++kx) {
+                    const float dv = d[ky >> 1][kx >> 1][e];      // tap (ky, kx) = class (ky & 1, kx & 1), neighbour (ky >> 1, kx >> 1)
+#pragma unroll
+                    for (int i = 0; i < CN; ++i) acc[(ky & 1) * 2 + (kx & 1)][i] = fmaf(dv, wc[(ky * 4 + kx) * CN + i], acc[(ky & 1) * 2 + (kx & 1)][i]);
+                }
         }
     }
-    const f32x4 r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    const int co = n0 + (lane & 3);
-    if (co < CN) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int pl = 4 * (lane >> 2) + v;                 // the lane whose pixel this register belongs to
-            const int m = ty0 + 2 * wave + (pl >> 5), n = tx0 + (pl & 31);
-            if (m < Hc && n < Wc) dxp[((size_t)(b * Hp + 2 * m + cy) * Wp + 2 * n + cx) * CN + co] = r[v];
+    for (int c = 0; c < 4; ++c) {
+        const int py = 2 * m + (c >> 1), px = 2 * n + (c & 1);
+        if (py < Hp && px < Wp) {
+            float* o = dxp + ((size_t)(b * Hp + py) * Wp + px) * CN;
+#pragma unroll
+            for (int i = 0; i < CN; ++i) o[i] = acc[c][i];
         }
     }
 }
@@ -708,11 +704,13 @@ int conv_fwd_small(const ConvGeom& g, const float* x, const float* w, const floa
 // dgrad of a thin-input 7x7 layer onto the padded grid dxp [B][H+6][W+6][Ci] (the caller folds the reflection)
 int conv_dgrad_small(const ConvGeom& g, const float* dy, const float* w, float* dxp, hipStream_t st) {
     // round 6: ... and of the first discriminator layers (4x4 stride 2 pad 1) onto [B][H+2][W+2][Ci]
-    if (small_enabled() && thin_enabled() && thin_in2_enabled() && !g.up && g.k == 4 && g.s == 2 && g.p == 1 && g.Ci <= 8 && g.Co % 8 == 0 && g.Hi % 2 == 0 && g.Wi % 2 == 0) {
-        const int Hc = (g.Hp + 1) / 2, Wc = (g.Wp + 1) / 2;      // the largest parity class
-        const int tx = cdiv(Wc, TW), ty = cdiv(Hc, TH);
-        hipLaunchKernelGGL(conv_thin_s2dg_kernel, dim3(g.B * tx * ty, 4, cdiv(g.Ci, 4)), dim3(256), 0, st, dy, w, dxp, g.Ho, g.Wo, g.Co, g.Ci, g.Hp, g.Wp, tx, ty);
-        ACL_CHECK_LAUNCH("conv_thin_s2dg_kernel");
+    if (small_enabled() && thin_enabled() && thin_in2_enabled() && !g.up && g.k == 4 && g.s == 2 && g.p == 1 && (g.Ci == 3 || g.Ci == 6) && g.Co % 4 == 0 &&
+        g.Hi % 2 == 0 && g.Wi % 2 == 0) {
+        const int64_t nthr = (int64_t)g.B * ((g.Hp + 1) / 2) * ((g.Wp + 1) / 2);
+        const dim3 grid((unsigned)cdiv64(nthr, 256));
+        if (g.Ci == 3) hipLaunchKernelGGL(conv_s2k4_thin_dgrad_kernel<3>, grid, dim3(256), 0, st, dy, w, dxp, g.B, g.Ho, g.Wo, g.Co, g.Hp, g.Wp);
+        else hipLaunchKernelGGL(conv_s2k4_thin_dgrad_kernel<6>, grid, dim3(256), 0, st, dy, w, dxp, g.B, g.Ho, g.Wo, g.Co, g.Hp, g.Wp);
+        ACL_CHECK_LAUNCH("conv_s2k4_thin_dgrad_kernel");
         return ACLGAN_OK;
     }
     if (!small_enabled() || !thin_enabled() || g.s != 1 || g.up || g.k != 7 || g.p != 3) return ACLGAN_EUNSUPPORTED;
