@@ -288,6 +288,8 @@ def main():
     ap.add_argument("--no-launch-floor", action="store_true", help="skip the 64x64 B=1 launch-bound probe (keeps kernel traces clean)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (the other single-GPU shapes of BASELINE.json, 5 steps each, after the timed region)")
     ap.add_argument("--lanes", type=int, default=None, help="streams the independent branches of an update are spread over (1 .. 3; default: the library's, ACLGAN_LANES or 3; 1 = one queue)")
+    ap.add_argument("--pre-streams", type=int, default=0, help="experiment (round 6): create this many HIP streams and run one kernel on each BEFORE the library creates "
+                    "its lane streams -- what a data-parallel process group (RCCL's stream) or a prefetching loader does to HIP's stream -> hardware-queue placement")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -360,6 +362,13 @@ def main():
         tw = int(os.environ["ACLGAN_BENCH_TEST_WIDTH"])     # networks narrow enough that gloo's host-side all-reduce does not dominate the test's wall time
         cfg["gen"].update(dim=tw, mlp_dim=2 * tw); cfg["dis"].update(dim=tw)
     torch.manual_seed(0)       # (replicas are made identical by the trainer's rank-0 broadcast, not by this seed)
+    pre_streams = []
+    for _ in range(max(0, args.pre_streams)):      # (kept alive for the whole run; each has seen work, so HIP has bound it to a hardware queue)
+        ps = torch.cuda.Stream(device="cuda:%d" % local_rank)
+        with torch.cuda.stream(ps):
+            torch.zeros(1024, device="cuda:%d" % local_rank).add_(1.0)
+        pre_streams.append(ps)
+    torch.cuda.synchronize()
     tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, deterministic=True if args.deterministic else None,
                         hip_graph=True if args.graph else None)
     B, S = args.batch, args.size
@@ -599,6 +608,7 @@ def main():
                        # gradient buckets are handed to RCCL from lane 0 = the caller's stream AFTER it has joined every lane and the
                        # parameter-gradient stream
                        "lanes": tuning_value(b"lanes"), "batched_filter_transforms": bool(tuning_value(b"u_batch")),
+                       "pre_streams": len(pre_streams),
                        "rccl": rccl_info},
             # frac = what the MFMA pipes really issue (EXECUTED FLOPs: Winograd F(4x4,3x3) runs the 3x3 convolutions with 1/4 of the
             # direct-convolution MACs, the sub-pixel path the upsample+5x5 layers with 9/25) over the dense matrix peak: a hardware

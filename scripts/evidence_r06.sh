@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/r06${TAG:+_$TAG}
 mkdir -p $O
 export TMPDIR=/tmp
-STAGES=${STAGES:-"tests smoke bench trace trace_ss0 trace16 trace16_ss0 traffic traffic16 traffic16f traffic512 pmcfused capture"}
+STAGES=${STAGES:-"tests smoke bench trace trace_ss0 trace16 trace16_ss0 traffic traffic16 traffic16f traffic512 pmcfused prestreams split thin s2k4 capture"}
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 B="python bench.py --no-cpu-baseline"
 summ() { python - "$1" <<'PY'
@@ -119,9 +119,24 @@ if has roctx; then
     head -50 $O/kernel_time_by_pass.txt | cut -c 1-150 | tee -a $O/progress.log
 fi
 if [ -n "${EXTRA:-}" ]; then echo "== extra: $EXTRA" | tee -a $O/progress.log; (eval "$EXTRA") 2>&1 | tail -${EXTRA_TAIL:-40} | tee -a $O/progress.log; fi
+if has prestreams; then      # round 6: does a foreign stream created first (RCCL's, a loader's) shift the lanes' hardware queues?  lanes x pre-streams
+    for ps in 0 1 2; do for ln in 2 3; do
+        $B --no-other-configs --no-launch-floor --steps 10 --warmup 3 --lanes $ln --pre-streams $ps > $O/bench_256_fp32_lanes${ln}_prestreams${ps}.json 2>/dev/null; summ $O/bench_256_fp32_lanes${ln}_prestreams${ps}.json | tee -a $O/progress.log
+    done; done
+fi
+if has split; then      # round 6, review item 4: the split-bf16 (6 products) inner loop against today's fp32 loop, register-resident
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Iscripts/microbench -o /tmp/split_bf16_loop scripts/microbench/split_bf16_loop.hip > $O/split_build.log 2>&1
+    timeout 300 /tmp/split_bf16_loop > $O/microbench_split_bf16_loop.txt 2>&1; cat $O/microbench_split_bf16_loop.txt | tee -a $O/progress.log
+fi
+if has thin; then      # round 6: the image-side layers in isolation, new kernels against ACLGAN_THININ2=0
+    (timeout 300 python scripts/probe_thin.py 10 2>&1 | grep -v amdgpu) > $O/probe_thin.txt; (ACLGAN_THININ2=0 timeout 300 python scripts/probe_thin.py 10 2>&1 | grep -v amdgpu) > $O/probe_thin_round5_kernels.txt
+    paste -d'|' $O/probe_thin.txt $O/probe_thin_round5_kernels.txt | cut -c 1-200 | tee -a $O/progress.log
+fi
+if has s2k4; then (timeout 300 python scripts/bench_s2k4.py 2>&1 | grep -v amdgpu) > $O/s2k4_direct_vs_fused_per_shape.txt; cat $O/s2k4_direct_vs_fused_per_shape.txt | tee -a $O/progress.log; fi
 if has capture; then      # round 6: minimal reproduction of the multi-stream capture crash (scripts/debug/capture_lanes.hip)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/capture_lanes scripts/debug/capture_lanes.hip > $O/capture_build.log 2>&1
     timeout 300 /tmp/capture_lanes > $O/capture_variants.txt 2>&1; paste - - < $O/capture_variants.txt | cut -c 1-160 | tee -a $O/progress.log
-    timeout 900 /tmp/capture_lanes sweep > $O/capture_sweep.txt 2>&1; paste - - < $O/capture_sweep.txt | cut -c 1-170 | tee -a $O/progress.log
+    timeout 600 /tmp/capture_lanes rings > $O/capture_rings.txt 2>&1; grep -c CRASHED $O/capture_rings.txt | tee -a $O/progress.log
+    timeout 900 /tmp/capture_lanes sweep > $O/capture_sweep.txt 2>&1; grep -c CRASHED $O/capture_sweep.txt | tee -a $O/progress.log
 fi
 echo "== done" | tee -a $O/progress.log
