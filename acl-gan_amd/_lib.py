@@ -81,6 +81,7 @@ SIGNATURES = {
     "aclgan_ctx_create": (ci, [C.POINTER(Arch), C.POINTER(vp)]),
     "aclgan_ctx_destroy": (None, [vp]),
     "aclgan_ctx_enable_capture": (ci, [vp]),
+    "aclgan_warm_streams": (ci, [ci]),
     "aclgan_debug_capture_masks": (ci, [vp, vp, sz]),
     "aclgan_debug_mask_count": (ci, [vp]),
     "aclgan_debug_mask_info": (ci, [vp, ci, C.POINTER(ci), C.POINTER(C.c_longlong), C.POINTER(ci)]),

@@ -958,7 +958,9 @@ static int prefill_wino_u(aclgan_ctx& c, int net, int B, int H, int W, bool trai
 // previous call's optimizer step wrote the parameters on the caller's stream.
 static int prefill_on_side_lane(aclgan_ctx& c, int B, int H, int W, bool train) {
     const int AB = ACLGAN_NET_GEN_AB, BA = ACLGAN_NET_GEN_BA;
-    if (c.nlanes <= 1) { CHK(prefill_wino_u(c, AB, B, H, W, train)); return prefill_wino_u(c, BA, B, H, W, train); }
+    static int on_lane = -1;      // ACLGAN_PREFILL_LANE=0: back in lane 0's preamble (A/B switch)
+    if (on_lane < 0) { const char* e = getenv("ACLGAN_PREFILL_LANE"); on_lane = (e && !atoi(e)) ? 0 : 1; }
+    if (c.nlanes <= 1 || !on_lane) { CHK(prefill_wino_u(c, AB, B, H, W, train)); return prefill_wino_u(c, BA, B, H, W, train); }
     const int LP = c.nlanes - 1;
     CHK(c.mark());
     const int k0 = c.nck(0) - 1;
@@ -1623,6 +1625,22 @@ void aclgan_ctx_destroy(aclgan_ctx* ctx) { delete ctx; }
 int aclgan_ctx_enable_capture(aclgan_ctx* ctx) {
     ACL_REQUIRE(ctx, "null ctx");
     return ctx->make_private_side();
+}
+
+// Round 6: create the process-wide streams of the lane scheduler (parameter-gradient stream, lanes 1 .. lanes - 1) on the CURRENT device NOW instead
+// of at the first update.  HIP binds streams to its 4 hardware queues in creation order: a stream another component creates first -- RCCL's, a
+// prefetching loader's -- takes a queue the lanes then have to share (measured with bench.py --pre-streams: one foreign stream first costs the
+// 3-lane step 3.7 ms, two cost 6.9 ms; profiles/r06_experiments.md section 8).  aclgan_Trainer calls this right after aclgan_ctx_create, before its
+// rank-0 broadcast initialises the process group's communicator.  Best effort: no device, nothing happens.
+int aclgan_warm_streams(int lanes) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ACLGAN_OK; }
+    if (!aclgan_ctx::side_enabled()) return ACLGAN_OK;
+    lanes = std::max(1, std::min(lanes <= 0 ? lanes_setting() : lanes, 3));
+    hipStream_t s = nullptr;
+    int rc = aclgan::StreamPool::of_device().get(0, &s);
+    for (int l = 1; l < lanes && rc == ACLGAN_OK; ++l) rc = aclgan::StreamPool::of_device().get(l, &s);
+    return rc;
 }
 
 int aclgan_debug_capture_masks(aclgan_ctx* ctx, unsigned char* dst, size_t cap_bytes) {

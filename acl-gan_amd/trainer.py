@@ -208,6 +208,11 @@ class aclgan_Trainer:
         self._ctx = C.c_void_p()
         L.check(L.lib.aclgan_ctx_create(C.byref(self.arch), C.byref(self._ctx)), "ctx_create")
         L.check(L.lib.aclgan_set_compute_dtype(self._ctx, L.DTYPE[self.compute_dtype]), "set_compute_dtype")
+        # the lane scheduler's streams first, before anything else of this process creates one (the rank-0 broadcast below initialises the process
+        # group's communicator and its stream): HIP binds streams to hardware queues in creation order (include/aclgan_hip.h, aclgan_warm_streams)
+        if os.environ.get("ACLGAN_WARM_STREAMS", "1") not in ("", "0"):
+            with torch.cuda.device(self.device):
+                L.check(L.lib.aclgan_warm_streams(0), "warm_streams")
         if self.hip_graph:      # (a captured update runs on one lane with a parameter-gradient stream of its own: created here, outside any capture)
             with torch.cuda.device(self.device):
                 L.check(L.lib.aclgan_ctx_enable_capture(self._ctx), "ctx_enable_capture")

@@ -290,6 +290,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=None, help="streams the independent branches of an update are spread over (1 .. 3; default: the library's, ACLGAN_LANES or 3; 1 = one queue)")
     ap.add_argument("--pre-streams", type=int, default=0, help="experiment (round 6): create this many HIP streams and run one kernel on each BEFORE the library creates "
                     "its lane streams -- what a data-parallel process group (RCCL's stream) or a prefetching loader does to HIP's stream -> hardware-queue placement")
+    ap.add_argument("--post-streams", type=int, default=0, help="experiment (round 6): ... or AFTER the trainer exists and before its first update (what a process group "
+                    "initialised by the trainer's rank-0 broadcast does)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -371,6 +373,12 @@ def main():
     torch.cuda.synchronize()
     tr = aclgan_Trainer(cfg, device="cuda:%d" % local_rank, compute_dtype=args.dtype, deterministic=True if args.deterministic else None,
                         hip_graph=True if args.graph else None)
+    for _ in range(max(0, args.post_streams)):
+        ps = torch.cuda.Stream(device="cuda:%d" % local_rank)
+        with torch.cuda.stream(ps):
+            torch.zeros(1024, device="cuda:%d" % local_rank).add_(1.0)
+        pre_streams.append(ps)
+    torch.cuda.synchronize()
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1 + rank)   # each rank its own shard of the synthetic global batch
     x_a = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()

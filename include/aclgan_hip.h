@@ -156,6 +156,11 @@ void aclgan_ctx_destroy(aclgan_ctx* ctx);
  * on (a captured update uses one lane; the process-wide lane streams are not captured).  Contexts that never capture should not call it:
  * every additional stream shifts HIP's stream -> hardware-queue placement (measured: 3 ms on the eager fp32 step). */
 int aclgan_ctx_enable_capture(aclgan_ctx* ctx);
+/* Round 6: create the lane scheduler's process-wide streams (the parameter-gradient stream and lanes 1 .. lanes - 1; lanes <= 0: the current
+ * "lanes" setting) on the CURRENT device now rather than at the first update.  HIP binds streams to its hardware queues in creation order;
+ * a host that creates other streams later (a process group's communicator, a prefetching loader) should call this first so that the lanes
+ * keep a queue each (measured: a foreign stream created before them costs the 3-lane step 3.7 ms).  Without a device: no effect. */
+int aclgan_warm_streams(int lanes);
 
 /* Diagnostics for the parity tests (round 6; tests/test_gpu_maskfrozen.py): record the ReLU / LeakyReLU masks the following updates run with.
  * Every Conv2dBlock (networks.py:365-371) an update back-propagates through appends (output > 0) of its activated output -- exactly the
