@@ -328,6 +328,15 @@ def main():
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit("rank %d: local GPU %d not visible (%d devices)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    # Round 6: the lane scheduler's streams BEFORE the process group exists.  HIP binds streams to its hardware queues in creation order;
+    # init_process_group(device_id=...) initialises RCCL's communicator (and its streams) eagerly, and a foreign stream created before the
+    # lanes' costs the 3-lane step 2.5 - 3.7 ms (profiles/r06_experiments.md section 8: --pre-streams / --post-streams).
+    import aclgan_amd  # noqa: F401  (raises if libaclgan_hip.so is missing)
+    from aclgan_amd import _lib as L
+    if args.lanes is not None:
+        L.check(L.lib.aclgan_tuning(b"lanes", args.lanes, None), "tuning lanes")
+    if os.environ.get("ACLGAN_WARM_STREAMS", "1") not in ("", "0") and not args.pre_streams:
+        L.check(L.lib.aclgan_warm_streams(0), "warm_streams")
     import torch.distributed as dist
     use_dist = world > 1 or os.environ.get("ACLGAN_BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
     rccl_log = None
@@ -347,12 +356,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    import aclgan_amd  # noqa: F401  (raises if libaclgan_hip.so is missing)
-    from aclgan_amd import _lib as L
     from aclgan_amd.trainer import aclgan_Trainer
     import ctypes as C
-    if args.lanes is not None:
-        L.check(L.lib.aclgan_tuning(b"lanes", args.lanes, None), "tuning lanes")
 
     def tuning_value(key):      # (read a switch; the getter changes nothing)
         v = C.c_longlong()

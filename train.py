@@ -57,6 +57,11 @@ def main():
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         sys.exit("rank %d: GPU %d not visible (%d devices); there is no CPU fallback" % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     torch.cuda.set_device(local_rank)
+    # the lane scheduler's streams before the process group's (HIP binds streams to hardware queues in creation order: include/aclgan_hip.h)
+    import aclgan_amd  # noqa: F401
+    from aclgan_amd import _lib as _L
+    if os.environ.get("ACLGAN_WARM_STREAMS", "1") not in ("", "0"):
+        _L.check(_L.lib.aclgan_warm_streams(0), "warm_streams")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
