@@ -163,36 +163,72 @@ __global__ void __launch_bounds__(256) conv_thin_out_kernel(const float* __restr
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < Cw; c0 += CH) {
-        __syncthreads();
-        for (int i = tid; i < PH * PW * 2; i += 256) {
+    // Round 6: the staging of 8-channel chunk c + 1 is FETCHED into registers before the tap loop of chunk c and written to LDS after it (until
+    // then every chunk exposed one global-load latency in front of its 392 MFMAs; profiles/r06_pmc_thin_layers.txt: waves parked 36 %).  The
+    // gather offsets do not depend on the chunk: computed once.
+    constexpr int NPP = (PH * PW * 2 + 255) / 256, NWP = (K * K * 4 * 2 + 255) / 256;
+    int poff[NPP], woff[NWP];
+#pragma unroll
+    for (int j = 0; j < NPP; ++j) {
+        const int i = tid + 256 * j;
+        poff[j] = -1;
+        if (i < PH * PW * 2) {
             const int pix = i >> 1, q = i & 1;
             const int py = pix / PW, px = pix - py * PW;
             const int gy = ty0 + py - P, gx = tx0 + px - P;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (MODE == 0) {
                 // clamp after reflecting: halo pixels of tiles that overhang the image feed only outputs that are never stored
                 const int iy = min(max(refl(gy, H), 0), H - 1), ix = min(max(refl(gx, W), 0), W - 1);
-                v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + iy) * W + ix) * Cw + c0 + q * 4);
+                poff[j] = ((b * H + iy) * W + ix) * Cw + q * 4;
             } else if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + gy) * W + gx) * Cw + c0 + q * 4);
+                poff[j] = ((b * H + gy) * W + gx) * Cw + q * 4;
             }
-            *reinterpret_cast<f32x4*>(patch + pix * PS + q * 4) = v;
         }
-        for (int i = tid; i < K * K * 4 * 2; i += 256) {
-            const int q = i & 1, n = (i >> 1) & 3, tap = i >> 3;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < CN) {
-                if (MODE == 0) {
-                    v = *reinterpret_cast<const f32x4*>(w + ((size_t)(n * K * K + tap)) * Cw + c0 + q * 4);
-                } else {
+    }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = w[((size_t)(c0 + q * 4 + e) * K * K + (K * K - 1 - tap)) * CN + n];
+    for (int j = 0; j < NWP; ++j) {
+        const int i = tid + 256 * j;
+        woff[j] = -1;
+        if (i < K * K * 4 * 2) {
+            const int q = i & 1, n = (i >> 1) & 3, tap = i >> 3;
+            if (n < CN) woff[j] = MODE == 0 ? (n * K * K + tap) * Cw + q * 4 : (q * 4 * K * K + (K * K - 1 - tap)) * CN + n;
+        }
+    }
+    f32x4 pr[NPP], wr[NWP];
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) {
+            pr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (poff[j] >= 0) pr[j] = *reinterpret_cast<const f32x4*>(in + (size_t)poff[j] + c0);
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (woff[j] >= 0) {
+                if (MODE == 0) v = *reinterpret_cast<const f32x4*>(w + (size_t)woff[j] + c0);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = w[(size_t)woff[j] + (size_t)(c0 + e) * K * K * CN];
                 }
             }
-            *reinterpret_cast<f32x4*>(wts + (tap * 4 + n) * CH + q * 4) = v;
+            wr[j] = v;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < Cw; c0 += CH) {
+        __syncthreads();                                  // the previous chunk's taps have read patch / wts
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) {
+            const int i = tid + 256 * j;
+            if (i < PH * PW * 2) *reinterpret_cast<f32x4*>(patch + (i >> 1) * PS + (i & 1) * 4) = pr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            const int i = tid + 256 * j;
+            if (i < K * K * 4 * 2) *reinterpret_cast<f32x4*>(wts + ((i >> 3) * 4 + ((i >> 1) & 3)) * CH + (i & 1) * 4) = wr[j];
         }
         __syncthreads();
+        if (c0 + CH < Cw) fetch(c0 + CH);                 // in flight under this chunk's tap loop
         const float* pa = patch + (ly * PW + lx) * PS;
         const float* pb = wts + (lane & 3) * CH;
 #pragma unroll 1
@@ -364,13 +400,29 @@ __global__ void __launch_bounds__(448) conv_wgrad_thin_kernel(const float* __res
     }
     // wide rows this workgroup walks: WIDE_X: padded rows qy = oy0 .. oy1+5 (x row refl(qy-3)); else output rows oy0 .. oy1-1 (dy)
     const int nwide = WIDE_X ? (oy1 - oy0) + 2 * P : (oy1 - oy0);
-    auto stage_wide = [&](int wr, int buf) {
+    // Round 6: the next wide row is FETCHED into registers before the MFMA loop of the current one and written to LDS after it.  (Until then the
+    // global load and its LDS store were one statement in front of the loop: every wide row exposed one global-load latency -- MFMA pipe 55 % busy,
+    // waves parked 33 %, profiles/r06_pmc_thin_layers.txt.)  THIN_SEG * 16 float4 over 448 threads: 3 per thread.
+    constexpr int NWR = (THIN_SEG * 16 + NT - 1) / NT;
+    f32x4 wreg[NWR];
+    auto fetch_wide = [&](int wr) __attribute__((always_inline)) {
         const int row = WIDE_X ? refl(oy0 + wr - P, H) : oy0 + wr;
         const float* src = (WIDE_X ? x : dy) + (size_t)(b * H + row) * W * 64;
-        for (int i = tid; i < npos * 16; i += NT) {
-            const int t = i >> 4, q = i & 15;
-            const int col = WIDE_X ? refl(s0 + t - P, W) : s0 + t;
-            *reinterpret_cast<f32x4*>(&wide[buf][t * 64 + q * 4]) = *reinterpret_cast<const f32x4*>(src + (size_t)col * 64 + q * 4);
+#pragma unroll
+        for (int j = 0; j < NWR; ++j) {
+            const int i = tid + j * NT;
+            if (i < npos * 16) {
+                const int t = i >> 4, q = i & 15;
+                const int col = WIDE_X ? refl(s0 + t - P, W) : s0 + t;
+                wreg[j] = *reinterpret_cast<const f32x4*>(src + (size_t)col * 64 + q * 4);
+            }
+        }
+    };
+    auto store_wide = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NWR; ++j) {
+            const int i = tid + j * NT;
+            if (i < npos * 16) *reinterpret_cast<f32x4*>(&wide[buf][(i >> 4) * 64 + (i & 15) * 4]) = wreg[j];
         }
     };
 
@@ -379,11 +431,11 @@ __global__ void __launch_bounds__(448) conv_wgrad_thin_kernel(const float* __res
     for (int i = 0; i < K; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    if (nwide > 0 && npos > 0) stage_wide(0, 0);
+    if (nwide > 0 && npos > 0) { fetch_wide(0); store_wide(0); }
     __syncthreads();
     for (int wr = 0; wr < nwide; ++wr) {
         const int buf = wr & 1;
-        if (wr + 1 < nwide) stage_wide(wr + 1, buf ^ 1);         // published by the barrier at the end of this iteration
+        if (wr + 1 < nwide) fetch_wide(wr + 1);                  // in flight under this row's MFMAs; stored below, published by the barrier
         // the thin row this wave (ky) pairs with wide row wr
         const int tr = WIDE_X ? wr - ky : wr + ky;               // WIDE_X: oy - oy0 = (qy - ky) - oy0
         const bool live = WIDE_X ? (tr >= 0 && tr < oy1 - oy0) : true;   // wave-uniform
@@ -411,6 +463,7 @@ __global__ void __launch_bounds__(448) conv_wgrad_thin_kernel(const float* __res
                 }
             }
         }
+        if (wr + 1 < nwide) store_wide(buf ^ 1);
         __syncthreads();
     }
     // lane l, register v of acc[kx] = dW[wide channel 4*(l/4)+v][thin channel l&3] of tap (ky, kx)
