@@ -458,14 +458,13 @@ __device__ __forceinline__ int fold_aliases(int u, int n, int p, int* q) {
 template <int V>
 __global__ void conv_fold_kernel(FoldP f) {
     typedef typename Vec<V>::T VT;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= f.total) return;
+    // grid (row blocks, Hi, B): the image row and the sample are block indices, one 32-bit division per thread (round 6; the flat 64-bit
+    // index cost four 64-bit divisions per element)
     const int cv = f.Ci / V;
-    const int c = (int)(idx % cv) * V;
-    int64_t pix = idx / cv;
-    const int j = (int)(pix % f.Wi); pix /= f.Wi;
-    const int i = (int)(pix % f.Hi);
-    const int b = (int)(pix / f.Hi);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= f.Wi * cv) return;
+    const int j = t / cv, c = (t - j * cv) * V;
+    const int i = blockIdx.y, b = blockIdx.z;
     float acc[V];
 #pragma unroll
     for (int t = 0; t < V; ++t) acc[t] = 0.f;
@@ -566,10 +565,10 @@ int conv_fold(const ConvGeom& g, const float* dxp, float* dx, int accumulate, hi
     f.Hp = g.Hp; f.Wp = g.Wp; f.p = g.p; f.up = g.up; f.accumulate = accumulate;
     if (g.Ci % 4 == 0) {
         f.total = (int64_t)g.B * g.Hi * g.Wi * (g.Ci / 4);
-        hipLaunchKernelGGL(conv_fold_kernel<4>, dim3((unsigned)cdiv64(f.total, 256)), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(conv_fold_kernel<4>, dim3((unsigned)cdiv(f.Wi * (f.Ci / 4), 256), f.Hi, f.B), dim3(256), 0, st, f);
     } else {
         f.total = (int64_t)g.B * g.Hi * g.Wi * g.Ci;
-        hipLaunchKernelGGL(conv_fold_kernel<1>, dim3((unsigned)cdiv64(f.total, 256)), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(conv_fold_kernel<1>, dim3((unsigned)cdiv(f.Wi * f.Ci, 256), f.Hi, f.B), dim3(256), 0, st, f);
     }
     ACL_CHECK_LAUNCH("conv_fold_kernel");
     return ACLGAN_OK;

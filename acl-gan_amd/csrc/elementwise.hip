@@ -81,12 +81,12 @@ __global__ void __launch_bounds__(256) norm_stats_kernel(const void* __restrict_
     // shift = the chunk's first pixel (kills the cancellation in sumsq - sum^2/n)
     const st_f32x4 sh = st_ld4(x, xb + (int64_t)p0 * C4 + cg, xst);
     float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
-    for (int p = p0 + pl; p < p1; p += PL) {
-        const st_f32x4 v = st_ld4(x, xb + (int64_t)p * C4 + cg, xst);
+    auto acc = [&](st_f32x4 v) __attribute__((always_inline)) {
         const float dx = v.x - sh.x, dy = v.y - sh.y, dz = v.z - sh.z, dw = v.w - sh.w;
         s.x += dx; s.y += dy; s.z += dz; s.w += dw;
         q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
-    }
+    };
+    for (int p = p0 + pl; p < p1; p += PL) acc(st_ld4(x, xb + (int64_t)p * C4 + cg, xst));
     __shared__ float4 rs[256], rq[256];
     rs[threadIdx.x] = s; rq[threadIdx.x] = q;
     __syncthreads();
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) norm_stats_kernel(const void* __restrict_
 
 // IN / AdaIN: combine chunk partials per (b,c); emit mean, rstd and the fused scale/shift.
 // One workgroup = one sample x 16 channels; threads are (channel lane, chunk lane) = 16 x 16 and every
-// thread keeps four independent loads in flight (the kernel is pure load latency: 128 chunks per image
+// thread keeps sixteen independent loads in flight (the kernel is pure load latency: 128 .. 256 chunks per image
 // on the 64x64 maps); the 16 chunk lanes are merged through LDS.
 __global__ void __launch_bounds__(256) norm_finalize_in_kernel(const float2* __restrict__ part, int C, int HW, int chunk, int nchunks,
                                                                const float* __restrict__ w, const float* __restrict__ bias, int w_stride,
@@ -118,19 +118,25 @@ __global__ void __launch_bounds__(256) norm_finalize_in_kernel(const float2* __r
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (c < C) {
         const float2* pb = part + (size_t)b * nchunks * C + c;
-        for (int k0 = kl; k0 < nchunks; k0 += 64) {
-            float2 v[4];
+        // U loads in flight per thread: 16 for the 256 tile-row chunks of a 64 x 64 map (one round of latency instead of four), 4 otherwise
+        // (same order of combination either way)
+        auto walk = [&](auto UC) __attribute__((always_inline)) {
+            constexpr int U = decltype(UC)::value;
+            for (int k0 = kl; k0 < nchunks; k0 += 16 * U) {
+                float2 v[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 16 * j;
-                v[j] = k < nchunks ? pb[(size_t)k * C] : make_float2(0.f, 0.f);
-            }
+                for (int j = 0; j < U; ++j) {
+                    const int k = k0 + 16 * j;
+                    v[j] = k < nchunks ? pb[(size_t)k * C] : make_float2(0.f, 0.f);
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 16 * j;
-                if (k < nchunks) chan_combine(n, mean, m2, (float)(min(HW, (k + 1) * chunk) - k * chunk), v[j].x, v[j].y);
+                for (int j = 0; j < U; ++j) {
+                    const int k = k0 + 16 * j;
+                    if (k < nchunks) chan_combine(n, mean, m2, (float)(min(HW, (k + 1) * chunk) - k * chunk), v[j].x, v[j].y);
+                }
             }
-        }
+        };
+        if (nchunks >= 256) walk(std::integral_constant<int, 16>()); else walk(std::integral_constant<int, 4>());
     }
     __shared__ float sn[16][16], sm[16][16], s2[16][16];
     sn[kl][cl] = n; sm[kl][cl] = mean; s2[kl][cl] = m2;
@@ -193,23 +199,58 @@ __global__ void __launch_bounds__(256) norm_finalize_ln_kernel(const float2* __r
     }
 }
 
-// y = act(x*scale[b][c] + shift[b][c]) (+ residual)
+// y = act(x*scale[b][c] + shift[b][c]) (+ residual).  Grid (gx, B): block row b is sample b, so no index is ever divided; 256 threads and
+// the grid stride are multiples of C/4 (a power of two <= 256), so a thread's channel quad -- and its eight coefficients -- are fixed:
+// loaded once.  NU float4 per operand in flight per thread.  (Round 6: the previous form -- one flat 64-bit index, i % C4 and
+// i / (HW * C4) per float4, one float4 per thread -- spent more issue slots on the two divisions than on the element and ran at 3.5 TB/s.)
+// SM: the storage code every operand shares (ST_F32 / ST_BF16 / ST_F16: the storage switch of st16.h is compiled out), or ST_MIXED = per-operand
+// run-time codes -- that form keeps one float4 in flight (unrolled, its branches cost more registers and issue slots than the loads win).
+constexpr int NU = 4;
+constexpr int ST_MIXED = 3;
+template <int SM>
 __global__ void __launch_bounds__(256) norm_apply_kernel(const void* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const void* __restrict__ res,
-                                                         void* __restrict__ y, NormST st, int HW, int C, int act, int64_t total4) {
-    const int C4 = C >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int cg = (int)(i % C4);
-        const int b = (int)(i / ((int64_t)HW * C4));
-        const float4 sc = *reinterpret_cast<const float4*>(scale + b * C + cg * 4);
-        const float4 sh = *reinterpret_cast<const float4*>(shift + b * C + cg * 4);
-        const st_f32x4 v = st_ld4(x, i, st.x);
-        st_f32x4 o;
-        o.x = act_fwd(fmaf(v.x, sc.x, sh.x), act); o.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
-        o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act); o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
-        if (res) { const st_f32x4 r = st_ld4(res, i, st.res); o += r; }
-        st_st4(y, i, o, st.y);
+                                                         void* __restrict__ y, NormST st, int per4, int C, int act) {
+    const int C4 = C >> 2, b = blockIdx.y;
+    const int o = b * C + (threadIdx.x & (C4 - 1)) * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + o);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + o);
+    const int64_t base = (int64_t)b * per4;
+    const int stride = gridDim.x * 256;
+    auto ld = [&](const void* p, int64_t i, int code) __attribute__((always_inline)) { return st_ld4(p, i, SM == ST_MIXED ? code : SM); };
+    auto one = [&](st_f32x4 v) __attribute__((always_inline)) {
+        st_f32x4 r;
+        r.x = act_fwd(fmaf(v.x, sc.x, sh.x), act); r.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
+        r.z = act_fwd(fmaf(v.z, sc.z, sh.z), act); r.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
+        return r;
+    };
+    auto put = [&](int64_t i, st_f32x4 v) __attribute__((always_inline)) { st_st4(y, i, v, SM == ST_MIXED ? st.y : SM); };
+    int i = blockIdx.x * 256 + threadIdx.x;
+    for (; SM != ST_MIXED && i + (NU - 1) * stride < per4; i += NU * stride) {
+        st_f32x4 v[NU], r[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) v[u] = ld(x, base + i + u * stride, st.x);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) r[u] = ld(res, base + i + u * stride, st.res);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            st_f32x4 q = one(v[u]);
+            if (res) q += r[u];
+            put(base + i + u * stride, q);
+        }
     }
+    for (; i < per4; i += stride) {
+        st_f32x4 q = one(ld(x, base + i, st.x));
+        if (res) q += ld(res, base + i, st.res);
+        put(base + i, q);
+    }
+}
+// workgroups per sample of the (gx, B) elementwise grids: NU float4 per thread, at most ~8192 workgroups in all
+static int rows_grid(int per4, int B) {
+    const int want = cdiv(per4, 256 * NU), cap = std::max(1, 8192 / std::max(1, B));
+    return std::max(1, std::min(want, cap));
 }
 
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -252,9 +293,14 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float
                            ww, bb, w_stride, mean, rstd, scale, shift);
     }
     ACL_CHECK_LAUNCH("norm_finalize");
-    const int64_t total4 = (int64_t)B * HW * C / 4;
-    const int grid = (int)std::min<int64_t>(cdiv64(total4, 256), 8192);
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(grid), dim3(256), 0, st, x, scale, shift, residual, y, sd, HW, C, act, total4);
+    ACL_REQUIRE((int64_t)HW * (C / 4) < 0x7fffff00ll, "norm: %d pixels x %d channels per sample", HW, C);
+    const int per4 = HW * (C / 4);
+    const dim3 grid(rows_grid(per4, B), B);
+    const int sm = (sd.x == sd.y && (!residual || sd.res == sd.x)) ? sd.x : ST_MIXED;
+    if (sm == ST_F32) hipLaunchKernelGGL(norm_apply_kernel<ST_F32>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
+    else if (sm == ST_BF16) hipLaunchKernelGGL(norm_apply_kernel<ST_BF16>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
+    else if (sm == ST_F16) hipLaunchKernelGGL(norm_apply_kernel<ST_F16>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
+    else hipLaunchKernelGGL(norm_apply_kernel<ST_MIXED>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
     ACL_CHECK_LAUNCH("norm_apply_kernel");
     return ACLGAN_OK;
 }
@@ -290,21 +336,23 @@ __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __rest
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     float4 ksc = make_float4(0, 0, 0, 0), ksh = ksc;
     if (msc) { ksc = *reinterpret_cast<const float4*>(msc + b * C + cg * 4); ksh = *reinterpret_cast<const float4*>(msh + b * C + cg * 4); }
-    for (int p = p0 + pl; p < p1; p += PL) {
-        const int64_t i = base + (int64_t)p * C4 + cg;
-        const st_f32x4 xv = st_ld4(x, i, st.x), gv = st_ld4(dy, i, st.dy);
-        st_f32x4 yv = {1.f, 1.f, 1.f, 1.f};
+    const bool need_y = act != ACLGAN_ACT_NONE && !msc;
+    auto acc = [&](st_f32x4 xv, st_f32x4 gv, st_f32x4 yv) __attribute__((always_inline)) {
         // act-less norms (2nd norm of every ResBlock): y is not needed.  ReLU / LeakyReLU with the forward's coefficients at hand (msc): the mask
         // is the sign of the forward's own fmaf(x, scale, shift) -- recomputed, the read of y is saved
-        if (act != ACLGAN_ACT_NONE) {
-            if (msc) { yv.x = fmaf(xv.x, ksc.x, ksh.x); yv.y = fmaf(xv.y, ksc.y, ksh.y); yv.z = fmaf(xv.z, ksc.z, ksh.z); yv.w = fmaf(xv.w, ksc.w, ksh.w); }
-            else yv = st_ld4(y, i, st.y);
-        }
+        if (msc && act != ACLGAN_ACT_NONE) { yv.x = fmaf(xv.x, ksc.x, ksh.x); yv.y = fmaf(xv.y, ksc.y, ksh.y); yv.z = fmaf(xv.z, ksc.z, ksh.z); yv.w = fmaf(xv.w, ksc.w, ksh.w); }
         const float g0 = gv.x * act_grad(yv.x, act), g1 = gv.y * act_grad(yv.y, act);
         const float g2 = gv.z * act_grad(yv.z, act), g3 = gv.w * act_grad(yv.w, act);
         s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
         s2.x += g0 * (xv.x - mu.x) * rs.x; s2.y += g1 * (xv.y - mu.y) * rs.y;
         s2.z += g2 * (xv.z - mu.z) * rs.z; s2.w += g3 * (xv.w - mu.w) * rs.w;
+    };
+    const st_f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+    // (round 6: four pixels' loads issued ahead of the sums measured SLOWER here -- 15.7 vs 14.8 us on the ResBlock maps, 47.8 vs 40.1 us on the
+    //  128 x 128 ones: the compiler already keeps the loads of consecutive iterations in flight, the hand-unrolled form only cost registers)
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const int64_t i = base + (int64_t)p * C4 + cg;
+        acc(st_ld4(x, i, st.x), st_ld4(dy, i, st.dy), need_y ? st_ld4(y, i, st.y) : ones);
     }
     __shared__ float4 r1[256], r2[256];
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
@@ -331,15 +379,15 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_in_kernel(const float2*
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
         const float2* pb = part + (size_t)b * nchunks * C + c;
-        for (int k0 = kl; k0 < nchunks; k0 += 64) {
-            float2 v[4];
+        for (int k0 = kl; k0 < nchunks; k0 += 128) {
+            float2 v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 const int k = k0 + 16 * j;
                 v[j] = k < nchunks ? pb[(size_t)k * C] : make_float2(0.f, 0.f);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s1 += v[j].x; s2 += v[j].y; }
+            for (int j = 0; j < 8; ++j) { s1 += v[j].x; s2 += v[j].y; }
         }
     }
     __shared__ float r1[16][16], r2[16][16];
@@ -416,37 +464,39 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_ln_kernel(const float2*
     }
 }
 
+// dx = A g + Bc xhat + Cc, g = dy act'(y) (+ the residual branch's gradient: dres (+)= g).  Same (gx, B) grid as norm_apply_kernel: the thread's
+// channel quad is fixed, its coefficients (mean, rstd, A, Bc, Cc, the forward's scale / shift) are loaded once, NU float4 per operand in flight
+// (SM as in norm_apply_kernel).
+template <int SM>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ y,
                                                              const void* __restrict__ dy, NormST st, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int per_channel_stats,
                                                              const float* __restrict__ cA, const float* __restrict__ cB,
                                                              const float* __restrict__ cC, void* __restrict__ dx,
-                                                             void* __restrict__ dres, int dres_acc, int HW, int C, int act,
-                                                             int64_t total4, const float* __restrict__ msc, const float* __restrict__ msh) {
-    const int C4 = C >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int cg = (int)(i % C4);
-        const int b = (int)(i / ((int64_t)HW * C4));
-        const int o = b * C + cg * 4;
-        float4 mu, rs;
-        if (per_channel_stats) {
-            mu = *reinterpret_cast<const float4*>(mean + o); rs = *reinterpret_cast<const float4*>(rstd + o);
-        } else {
-            const float m = mean[b], r = rstd[b];
-            mu = make_float4(m, m, m, m); rs = make_float4(r, r, r, r);
-        }
-        const float4 a = *reinterpret_cast<const float4*>(cA + o);
-        const float4 kb = *reinterpret_cast<const float4*>(cB + o);
-        const float4 kc = *reinterpret_cast<const float4*>(cC + o);
-        const st_f32x4 xv = st_ld4(x, i, st.x), gv = st_ld4(dy, i, st.dy);
-        st_f32x4 yv = {1.f, 1.f, 1.f, 1.f};
-        if (act != ACLGAN_ACT_NONE) {
-            if (msc) {
-                const float4 ksc = *reinterpret_cast<const float4*>(msc + o), ksh = *reinterpret_cast<const float4*>(msh + o);
-                yv.x = fmaf(xv.x, ksc.x, ksh.x); yv.y = fmaf(xv.y, ksc.y, ksh.y); yv.z = fmaf(xv.z, ksc.z, ksh.z); yv.w = fmaf(xv.w, ksc.w, ksh.w);
-            } else yv = st_ld4(y, i, st.y);
-        }
-        st_f32x4 g;
+                                                             void* __restrict__ dres, int dres_acc, int per4, int C, int act,
+                                                             const float* __restrict__ msc, const float* __restrict__ msh) {
+    const int C4 = C >> 2, b = blockIdx.y;
+    const int o = b * C + (threadIdx.x & (C4 - 1)) * 4;
+    float4 mu, rs;
+    if (per_channel_stats) {
+        mu = *reinterpret_cast<const float4*>(mean + o); rs = *reinterpret_cast<const float4*>(rstd + o);
+    } else {
+        const float m = mean[b], r = rstd[b];
+        mu = make_float4(m, m, m, m); rs = make_float4(r, r, r, r);
+    }
+    const float4 a = *reinterpret_cast<const float4*>(cA + o);
+    const float4 kb = *reinterpret_cast<const float4*>(cB + o);
+    const float4 kc = *reinterpret_cast<const float4*>(cC + o);
+    float4 ksc = make_float4(0, 0, 0, 0), ksh = ksc;
+    const bool need_y = act != ACLGAN_ACT_NONE, from_x = need_y && msc != nullptr;
+    if (from_x) { ksc = *reinterpret_cast<const float4*>(msc + o); ksh = *reinterpret_cast<const float4*>(msh + o); }
+    const int64_t base = (int64_t)b * per4;
+    const int stride = gridDim.x * 256;
+    auto ld = [&](const void* p, int64_t i, int code) __attribute__((always_inline)) { return st_ld4(p, i, SM == ST_MIXED ? code : SM); };
+    auto put = [&](void* p, int64_t i, st_f32x4 v, int code) __attribute__((always_inline)) { st_st4(p, i, v, SM == ST_MIXED ? code : SM); };
+    // g and dx of one float4 (yv: the activation's output, or -- from_x -- recomputed as the forward's own fmaf)
+    auto one = [&](st_f32x4 xv, st_f32x4 gv, st_f32x4 yv, st_f32x4& g) __attribute__((always_inline)) {
+        if (from_x) { yv.x = fmaf(xv.x, ksc.x, ksh.x); yv.y = fmaf(xv.y, ksc.y, ksh.y); yv.z = fmaf(xv.z, ksc.z, ksh.z); yv.w = fmaf(xv.w, ksc.w, ksh.w); }
         g.x = gv.x * act_grad(yv.x, act); g.y = gv.y * act_grad(yv.y, act);
         g.z = gv.z * act_grad(yv.z, act); g.w = gv.w * act_grad(yv.w, act);
         st_f32x4 d;
@@ -454,10 +504,42 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restr
         d.y = fmaf(a.y, g.y, fmaf(kb.y, (xv.y - mu.y) * rs.y, kc.y));
         d.z = fmaf(a.z, g.z, fmaf(kb.z, (xv.z - mu.z) * rs.z, kc.z));
         d.w = fmaf(a.w, g.w, fmaf(kb.w, (xv.w - mu.w) * rs.w, kc.w));
-        st_st4(dx, i, d, st.dx);
+        return d;
+    };
+    const st_f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+    int i = blockIdx.x * 256 + threadIdx.x;
+    for (; SM != ST_MIXED && i + (NU - 1) * stride < per4; i += NU * stride) {
+        st_f32x4 xv[NU], gv[NU], yv[NU], rv[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { xv[u] = ld(x, base + i + u * stride, st.x); gv[u] = ld(dy, base + i + u * stride, st.dy); yv[u] = ones; }
+        if (need_y && !from_x) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) yv[u] = ld(y, base + i + u * stride, st.y);
+        }
+        if (dres && dres_acc) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) rv[u] = ld(dres, base + i + u * stride, st.dres);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            st_f32x4 g;
+            const st_f32x4 d = one(xv[u], gv[u], yv[u], g);
+            put(dx, base + i + u * stride, d, st.dx);
+            if (dres) {
+                if (dres_acc) g += rv[u];
+                put(dres, base + i + u * stride, g, st.dres);
+            }
+        }
+    }
+    for (; i < per4; i += stride) {
+        const st_f32x4 xv = ld(x, base + i, st.x), gv = ld(dy, base + i, st.dy);
+        const st_f32x4 yv = (need_y && !from_x) ? ld(y, base + i, st.y) : ones;
+        st_f32x4 g;
+        const st_f32x4 d = one(xv, gv, yv, g);
+        put(dx, base + i, d, st.dx);
         if (dres) {
-            if (dres_acc) g += st_ld4(dres, i, st.dres);
-            st_st4(dres, i, g, st.dres);
+            if (dres_acc) g += ld(dres, base + i, st.dres);
+            put(dres, base + i, g, st.dres);
         }
     }
 }
@@ -494,10 +576,18 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
                        rstd, cA, cB, cC, kind == ACLGAN_NORM_ADAIN ? dw : nullptr, kind == ACLGAN_NORM_ADAIN ? db : nullptr);
     ACL_CHECK_LAUNCH("norm_bwd_finalize_in_kernel");
     }
-    const int64_t total4 = (int64_t)B * HW * C / 4;
-    const int grid = (int)std::min<int64_t>(cdiv64(total4, 256), 8192);
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, cA, cB, cC, dx, dres, dres_accumulate,
-                       HW, C, act, total4, msc, msh);
+    ACL_REQUIRE((int64_t)HW * (C / 4) < 0x7fffff00ll, "norm: %d pixels x %d channels per sample", HW, C);
+    const int per4 = HW * (C / 4);
+    const dim3 grid(rows_grid(per4, B), B);
+    const bool need_y = act != ACLGAN_ACT_NONE && !msc;
+    const int sm = (sd.dy == sd.x && sd.dx == sd.x && (!need_y || sd.y == sd.x) && (!dres || sd.dres == sd.x)) ? sd.x : ST_MIXED;
+#define ACL_NBA(SM) hipLaunchKernelGGL(norm_bwd_apply_kernel<SM>, grid, dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, cA, cB, cC, dx, dres, \
+                                       dres_accumulate, per4, C, act, msc, msh)
+    if (sm == ST_F32) ACL_NBA(ST_F32);
+    else if (sm == ST_BF16) ACL_NBA(ST_BF16);
+    else if (sm == ST_F16) ACL_NBA(ST_F16);
+    else ACL_NBA(ST_MIXED);
+#undef ACL_NBA
     ACL_CHECK_LAUNCH("norm_bwd_apply_kernel");
     return ACLGAN_OK;
 }

@@ -48,8 +48,37 @@ __global__ void act_bwd_st_kernel(const void* __restrict__ y, int yst, void* __r
         st_st4(dy, i, g, gst);
     }
 }
+// fp32, 16-byte aligned, n % 4 == 0: float4 accesses, four of them in flight per operand (round 6: the scalar form moved 4.8 TB/s)
+__global__ void __launch_bounds__(256) act_bwd_v4_kernel(const st_f32x4* __restrict__ y, st_f32x4* __restrict__ dy, int act, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        st_f32x4 yv[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { yv[u] = y[i + u * stride]; g[u] = dy[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[u][e] *= act_grad_m(yv[u][e], act);
+            dy[i + u * stride] = g[u];
+        }
+    }
+    for (; i < n4; i += stride) {
+        const st_f32x4 yv = y[i];
+        st_f32x4 g = dy[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= act_grad_m(yv[e], act);
+        dy[i] = g;
+    }
+}
 int act_bwd_inplace(int act, const void* y, void* dy, int64_t n, hipStream_t st, int yst, int gst) {
     if (act == ACLGAN_ACT_NONE || n == 0) return ACLGAN_OK;
+    if (yst == ST_F32 && gst == ST_F32 && n % 4 == 0 && (((uintptr_t)y | (uintptr_t)dy) & 15) == 0) {
+        const int grid = (int)std::min<int64_t>(cdiv64(n / 4, 256 * 4), 8192);
+        hipLaunchKernelGGL(act_bwd_v4_kernel, dim3(std::max(grid, 1)), dim3(256), 0, st, (const st_f32x4*)y, (st_f32x4*)dy, act, n / 4);
+        ACL_CHECK_LAUNCH("act_bwd_v4_kernel");
+        return ACLGAN_OK;
+    }
     if (yst == ST_F32 && gst == ST_F32) {
         const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 8192);
         hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, st, (const float*)y, (float*)dy, act, n);
