@@ -69,10 +69,19 @@ static int norm_chunk_pixels(int B, int HW) {
     return c;
 }
 
+// Storage template parameter of the streaming kernels below: SM = the storage code every operand shares (ST_F32 / ST_BF16 / ST_F16: the switch
+// of st16.h is compiled out), or ST_MIXED = per-operand run-time codes.  Only the compiled-in forms keep NU loads per operand in flight: with
+// run-time codes every load sits in its own branch and is waited for at the branch's end, so unrolling buys registers and nothing else
+// (measured, round 6: the hand-unrolled reduce with run-time codes was 6 .. 19 % SLOWER than the plain loop).
+constexpr int NU = 4;
+constexpr int ST_MIXED = 3;
+
 // partial statistics: part[b][chunk][c] = (mean, M2) over the chunk's pixels.  Threads are laid
 // out C/4 float4-lanes wide (coalesced 16 B/lane along the channel axis), 256/(C/4) pixels deep.
-__global__ void __launch_bounds__(256) norm_stats_kernel(const void* __restrict__ x, int xst, float2* __restrict__ part,
+template <int SM>
+__global__ void __launch_bounds__(256) norm_stats_kernel(const void* __restrict__ x, int xst_rt, float2* __restrict__ part,
                                                          int HW, int C, int chunk, int nchunks) {
+    const int xst = SM == ST_MIXED ? xst_rt : SM;
     const int C4 = C >> 2;
     const int b = blockIdx.y, ch = blockIdx.x;
     const int p0 = ch * chunk, p1 = min(HW, p0 + chunk);
@@ -86,7 +95,15 @@ __global__ void __launch_bounds__(256) norm_stats_kernel(const void* __restrict_
         s.x += dx; s.y += dy; s.z += dz; s.w += dw;
         q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
     };
-    for (int p = p0 + pl; p < p1; p += PL) acc(st_ld4(x, xb + (int64_t)p * C4 + cg, xst));
+    int p = p0 + pl;
+    for (; SM != ST_MIXED && p + (NU - 1) * PL < p1; p += NU * PL) {      // NU loads in flight, added in the order of the plain loop (same bits)
+        st_f32x4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) v[u] = st_ld4(x, xb + (int64_t)(p + u * PL) * C4 + cg, xst);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc(v[u]);
+    }
+    for (; p < p1; p += PL) acc(st_ld4(x, xb + (int64_t)p * C4 + cg, xst));
     __shared__ float4 rs[256], rq[256];
     rs[threadIdx.x] = s; rq[threadIdx.x] = q;
     __syncthreads();
@@ -116,33 +133,68 @@ __global__ void __launch_bounds__(256) norm_finalize_in_kernel(const float2* __r
     const int b = blockIdx.y, cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
+    // eq: every chunk holds `chunk` pixels and the 16 chunk lanes see the same number of chunks (always so behind a convolution epilogue).  Then K
+    // equal-count partials combine as mean = avg(mean_k), M2 = sum M2_k + count * sum (mean_k - mean)^2: no divisions and no serial dependence --
+    // Chan's pairwise form costs two divisions per partial, 31 of them in a row per channel here (measured 8.4 us per launch against 4.7 us for
+    // the backward's finalize, which only adds; 141 launches per step on the convolution chains).
+    const bool eq = HW % chunk == 0 && nchunks % 16 == 0;
     if (c < C) {
         const float2* pb = part + (size_t)b * nchunks * C + c;
-        // U loads in flight per thread: 16 for the 256 tile-row chunks of a 64 x 64 map (one round of latency instead of four), 4 otherwise
-        // (same order of combination either way)
-        auto walk = [&](auto UC) __attribute__((always_inline)) {
-            constexpr int U = decltype(UC)::value;
-            for (int k0 = kl; k0 < nchunks; k0 += 16 * U) {
-                float2 v[U];
+        if (eq) {
+            for (int k0 = kl; k0 < nchunks; k0 += 256) {      // rounds of <= 16 partials held in registers (one round on the 64 x 64 maps)
+                float2 v[16];
+                int cnt = 0;
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
+                for (int j = 0; j < 16; ++j) {
                     const int k = k0 + 16 * j;
                     v[j] = k < nchunks ? pb[(size_t)k * C] : make_float2(0.f, 0.f);
+                    cnt += k < nchunks ? 1 : 0;
                 }
+                float sm_ = 0.f, sq = 0.f, sd2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const int k = k0 + 16 * j;
-                    if (k < nchunks) chan_combine(n, mean, m2, (float)(min(HW, (k + 1) * chunk) - k * chunk), v[j].x, v[j].y);
-                }
+                for (int j = 0; j < 16; ++j) { sm_ += v[j].x; sq += v[j].y; }
+                const float mr = sm_ / (float)cnt;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { const float d = v[j].x - mr; sd2 += (k0 + 16 * j < nchunks) ? d * d : 0.f; }
+                chan_combine(n, mean, m2, (float)(cnt * chunk), mr, fmaf((float)chunk, sd2, sq));
             }
-        };
-        if (nchunks >= 256) walk(std::integral_constant<int, 16>()); else walk(std::integral_constant<int, 4>());
+        } else {
+            // U loads in flight per thread: 16 for >= 256 chunks, 4 otherwise (same order of combination either way)
+            auto walk = [&](auto UC) __attribute__((always_inline)) {
+                constexpr int U = decltype(UC)::value;
+                for (int k0 = kl; k0 < nchunks; k0 += 16 * U) {
+                    float2 v[U];
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        const int k = k0 + 16 * j;
+                        v[j] = k < nchunks ? pb[(size_t)k * C] : make_float2(0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        const int k = k0 + 16 * j;
+                        if (k < nchunks) chan_combine(n, mean, m2, (float)(min(HW, (k + 1) * chunk) - k * chunk), v[j].x, v[j].y);
+                    }
+                }
+            };
+            if (nchunks >= 256) walk(std::integral_constant<int, 16>()); else walk(std::integral_constant<int, 4>());
+        }
     }
     __shared__ float sn[16][16], sm[16][16], s2[16][16];
     sn[kl][cl] = n; sm[kl][cl] = mean; s2[kl][cl] = m2;
     __syncthreads();
     if (kl != 0 || c >= C) return;
-    for (int j = 1; j < 16; ++j) chan_combine(n, mean, m2, sn[j][cl], sm[j][cl], s2[j][cl]);
+    if (eq) {      // the 16 chunk lanes hold equal counts
+        float sm_ = 0.f, sq = 0.f, sd2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sm_ += sm[j][cl]; sq += s2[j][cl]; }
+        mean = sm_ * (1.f / 16.f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float d = sm[j][cl] - mean; sd2 += d * d; }
+        m2 = fmaf(n, sd2, sq);
+        n *= 16.f;
+    } else {
+        for (int j = 1; j < 16; ++j) chan_combine(n, mean, m2, sn[j][cl], sm[j][cl], s2[j][cl]);
+    }
     const int i = b * C + c;
     const float rstd = rsqrtf(m2 / n + 1e-5f);
     mean_o[i] = mean; rstd_o[i] = rstd;
@@ -152,26 +204,29 @@ __global__ void __launch_bounds__(256) norm_finalize_in_kernel(const float2* __r
     shift[i] = bb - mean * rstd * ww;
 }
 
-// LN: one workgroup per sample combines all (chunk, channel) partials; unbiased std, eps on the std.
-__global__ void __launch_bounds__(256) norm_finalize_ln_kernel(const float2* __restrict__ part, int C, int HW, int chunk,
-                                                               int nchunks, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float* __restrict__ mean_o,
-                                                               float* __restrict__ rstd_o, float* __restrict__ scale,
-                                                               float* __restrict__ shift) {
-    const int b = blockIdx.x;
+// LN statistics, stage 1 of 2 (round 6): workgroup (s, b) combines slice s of sample b's (chunk, channel) partials into one (count, mean, M2)
+// triple, lnpart[b][s].  Stage 2 lives in norm_apply_kernel<.., true>: every workgroup combines the <= 64 triples of its sample itself.
+// (Before: ONE workgroup per sample walked all partials -- 1 MB per sample behind the fused up-sampling convolutions, 64 rounds of load
+// latency: 17 .. 32 us per layer on the decoder's critical path.)
+constexpr int LN_SLICES = 64;
+static int ln_slices(int items) { return std::max(1, std::min(LN_SLICES, items / 2048)); }
+__global__ void __launch_bounds__(256) norm_finalize_ln_part_kernel(const float2* __restrict__ part, int C, int HW, int chunk, int nchunks,
+                                                                    int per, float4* __restrict__ lnpart) {
+    const int b = blockIdx.y, sl = blockIdx.x;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     const int items = nchunks * C;
-    for (int i0 = threadIdx.x; i0 < items; i0 += 256 * 8) {   // eight loads in flight per thread
+    const int i_end = min(items, (sl + 1) * per);
+    for (int i0 = sl * per + threadIdx.x; i0 < i_end; i0 += 256 * 8) {   // eight loads in flight per thread
         float2 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int i = i0 + 256 * j;
-            v[j] = i < items ? part[(size_t)b * items + i] : make_float2(0.f, 0.f);
+            v[j] = i < i_end ? part[(size_t)b * items + i] : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int i = i0 + 256 * j;
-            if (i < items) {
+            if (i < i_end) {
                 const int k = i / C;
                 chan_combine(n, mean, m2, (float)(min(HW, (k + 1) * chunk) - k * chunk), v[j].x, v[j].y);
             }
@@ -188,15 +243,23 @@ __global__ void __launch_bounds__(256) norm_finalize_ln_kernel(const float2* __r
         }
         __syncthreads();
     }
-    const float N = sn[0], mu = sm[0];
-    const float sd = sqrtf(s2[0] / (N - 1.f));
-    const float t = 1.f / (sd + 1e-5f);
-    if (threadIdx.x == 0) { mean_o[b] = mu; rstd_o[b] = t; }
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float g = gamma[c];
-        scale[b * C + c] = t * g;
-        shift[b * C + c] = beta[c] - mu * t * g;
+    if (threadIdx.x == 0) lnpart[b * gridDim.x + sl] = make_float4(sn[0], sm[0], s2[0], 0.f);
+}
+// stage 2, per wave: lane l holds triple l (or nothing), a butterfly of Chan combinations, then EVERY lane takes lane 0's result -- the
+// combination is not commutative to the last bit, and all threads of all workgroups must apply the very same coefficients (norm_bwd recomputes
+// the activation mask from the stored ones).  Unbiased std, eps on the std (networks.py:520-536).
+__device__ __forceinline__ void ln_totals(const float4* __restrict__ lnpart, int b, int S, float& mu, float& t) {
+    const int lane = threadIdx.x & 63;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (lane < S) { const float4 v = lnpart[b * S + lane]; n = v.x; mean = v.y; m2 = v.z; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
+        chan_combine(n, mean, m2, nb, mb, qb);
     }
+    n = __shfl(n, 0); mean = __shfl(mean, 0); m2 = __shfl(m2, 0);
+    const float sd = sqrtf(m2 / (n - 1.f));
+    mu = mean; t = 1.f / (sd + 1e-5f);
 }
 
 // y = act(x*scale[b][c] + shift[b][c]) (+ residual).  Grid (gx, B): block row b is sample b, so no index is ever divided; 256 threads and
@@ -205,16 +268,30 @@ __global__ void __launch_bounds__(256) norm_finalize_ln_kernel(const float2* __r
 // i / (HW * C4) per float4, one float4 per thread -- spent more issue slots on the two divisions than on the element and ran at 3.5 TB/s.)
 // SM: the storage code every operand shares (ST_F32 / ST_BF16 / ST_F16: the storage switch of st16.h is compiled out), or ST_MIXED = per-operand
 // run-time codes -- that form keeps one float4 in flight (unrolled, its branches cost more registers and issue slots than the loads win).
-constexpr int NU = 4;
-constexpr int ST_MIXED = 3;
-template <int SM>
-__global__ void __launch_bounds__(256) norm_apply_kernel(const void* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const void* __restrict__ res,
-                                                         void* __restrict__ y, NormST st, int per4, int C, int act) {
+// LN = true: scale / shift are OUTPUTS -- the workgroup derives them from the sample's LayerNorm triples (ln_totals) and gamma / beta, and
+// workgroup 0 of the sample stores them with mean / rstd for the backward.
+struct LnArgs { const float4* part; int S; const float* gamma; const float* beta; float* mean_o; float* rstd_o; };
+template <int SM, bool LN>
+__global__ void __launch_bounds__(256) norm_apply_kernel(const void* __restrict__ x, float* __restrict__ scale,
+                                                         float* __restrict__ shift, const void* __restrict__ res,
+                                                         void* __restrict__ y, NormST st, int per4, int C, int act, LnArgs ln) {
     const int C4 = C >> 2, b = blockIdx.y;
-    const int o = b * C + (threadIdx.x & (C4 - 1)) * 4;
-    const float4 sc = *reinterpret_cast<const float4*>(scale + o);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + o);
+    const int cq = (threadIdx.x & (C4 - 1)) * 4, o = b * C + cq;
+    float4 sc, sh;
+    if (LN) {
+        float mu, t;
+        ln_totals(ln.part, b, ln.S, mu, t);
+        const float4 g = *reinterpret_cast<const float4*>(ln.gamma + cq), be = *reinterpret_cast<const float4*>(ln.beta + cq);
+        sc = make_float4(t * g.x, t * g.y, t * g.z, t * g.w);
+        sh = make_float4(be.x - mu * t * g.x, be.y - mu * t * g.y, be.z - mu * t * g.z, be.w - mu * t * g.w);
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) { ln.mean_o[b] = mu; ln.rstd_o[b] = t; }
+            if ((int)threadIdx.x < C4) { *reinterpret_cast<float4*>(scale + o) = sc; *reinterpret_cast<float4*>(shift + o) = sh; }
+        }
+    } else {
+        sc = *reinterpret_cast<const float4*>(scale + o);
+        sh = *reinterpret_cast<const float4*>(shift + o);
+    }
     const int64_t base = (int64_t)b * per4;
     const int stride = gridDim.x * 256;
     auto ld = [&](const void* p, int64_t i, int code) __attribute__((always_inline)) { return st_ld4(p, i, SM == ST_MIXED ? code : SM); };
@@ -258,7 +335,8 @@ static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 size_t norm_scratch_bytes(int B, int HW, int C) {
     const int chunk = norm_chunk_pixels(B, HW);
     const int nchunks = cdiv(HW, chunk);
-    return (size_t)B * nchunks * C * sizeof(float2) + (size_t)B * C * 5 * sizeof(float) + 256;
+    // chunk partials | scale, shift (forward) or A, Bc, Cc (+ LN totals) (backward) | the LayerNorm slice triples (forward) | slack
+    return (size_t)B * nchunks * C * sizeof(float2) + (size_t)B * C * 5 * sizeof(float) + (size_t)B * LN_SLICES * sizeof(float4) + 256;
 }
 
 // stats != nullptr: the producer of x already wrote the chunk partials [B][HW / stats_chunk][C] (mean, M2) -- conv_fwd's epilogue
@@ -279,12 +357,18 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float
     float* scale = ss_out ? ss_out : (float*)((float2*)scratch + (size_t)B * cdiv(HW, own_chunk) * C);
     float* shift = scale + (size_t)B * C;
     if (!stats) {
-        hipLaunchKernelGGL(norm_stats_kernel, dim3(nchunks, B), dim3(256), 0, st, x, sd.x, part, HW, C, chunk, nchunks);
+        if (sd.x == ST_F32) hipLaunchKernelGGL(norm_stats_kernel<ST_F32>, dim3(nchunks, B), dim3(256), 0, st, x, sd.x, part, HW, C, chunk, nchunks);
+        else if (sd.x == ST_BF16) hipLaunchKernelGGL(norm_stats_kernel<ST_BF16>, dim3(nchunks, B), dim3(256), 0, st, x, sd.x, part, HW, C, chunk, nchunks);
+        else hipLaunchKernelGGL(norm_stats_kernel<ST_F16>, dim3(nchunks, B), dim3(256), 0, st, x, sd.x, part, HW, C, chunk, nchunks);
         ACL_CHECK_LAUNCH("norm_stats_kernel");
     }
+    LnArgs ln = {nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (kind == ACLGAN_NORM_LN) {
         ACL_REQUIRE(w && b, "LN needs gamma/beta");
-        hipLaunchKernelGGL(norm_finalize_ln_kernel, dim3(B), dim3(256), 0, st, part, C, HW, chunk, nchunks, w, b, mean, rstd, scale, shift);
+        const int items = nchunks * C, S = ln_slices(items), per = cdiv(items, S);
+        float4* lnpart = (float4*)((char*)scratch + norm_scratch_bytes(B, HW, C) - 256 - (size_t)B * LN_SLICES * sizeof(float4));
+        hipLaunchKernelGGL(norm_finalize_ln_part_kernel, dim3(S, B), dim3(256), 0, st, part, C, HW, chunk, nchunks, per, lnpart);
+        ln = LnArgs{lnpart, S, w, b, mean, rstd};
     } else {
         const float* ww = kind == ACLGAN_NORM_ADAIN ? w : nullptr;
         const float* bb = kind == ACLGAN_NORM_ADAIN ? b : nullptr;
@@ -297,10 +381,13 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float
     const int per4 = HW * (C / 4);
     const dim3 grid(rows_grid(per4, B), B);
     const int sm = (sd.x == sd.y && (!residual || sd.res == sd.x)) ? sd.x : ST_MIXED;
-    if (sm == ST_F32) hipLaunchKernelGGL(norm_apply_kernel<ST_F32>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
-    else if (sm == ST_BF16) hipLaunchKernelGGL(norm_apply_kernel<ST_BF16>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
-    else if (sm == ST_F16) hipLaunchKernelGGL(norm_apply_kernel<ST_F16>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
-    else hipLaunchKernelGGL(norm_apply_kernel<ST_MIXED>, grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act);
+#define ACL_NA(SM, LN) hipLaunchKernelGGL((norm_apply_kernel<SM, LN>), grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act, ln)
+    if (kind == ACLGAN_NORM_LN) {
+        if (sm == ST_F32) ACL_NA(ST_F32, true); else if (sm == ST_BF16) ACL_NA(ST_BF16, true); else if (sm == ST_F16) ACL_NA(ST_F16, true); else ACL_NA(ST_MIXED, true);
+    } else {
+        if (sm == ST_F32) ACL_NA(ST_F32, false); else if (sm == ST_BF16) ACL_NA(ST_BF16, false); else if (sm == ST_F16) ACL_NA(ST_F16, false); else ACL_NA(ST_MIXED, false);
+    }
+#undef ACL_NA
     ACL_CHECK_LAUNCH("norm_apply_kernel");
     return ACLGAN_OK;
 }
@@ -315,6 +402,7 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float
 //             dx = t*(dxhat - S1_b/n) - xhat*S2_b/((n-1)*std);  dgamma_c += sum_b s2;  dbeta_c += sum_b s1
 //   both written as dx = A[b][c]*g + Bc[b][c]*xhat + Cc[b][c]
 // ------------------------------------------------------------------------------------------
+template <int SM>
 __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __restrict__ x, const void* __restrict__ y,
                                                               const void* __restrict__ dy, NormST st, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int per_channel_stats,
@@ -348,11 +436,25 @@ __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __rest
         s2.z += g2 * (xv.z - mu.z) * rs.z; s2.w += g3 * (xv.w - mu.w) * rs.w;
     };
     const st_f32x4 ones = {1.f, 1.f, 1.f, 1.f};
-    // (round 6: four pixels' loads issued ahead of the sums measured SLOWER here -- 15.7 vs 14.8 us on the ResBlock maps, 47.8 vs 40.1 us on the
-    //  128 x 128 ones: the compiler already keeps the loads of consecutive iterations in flight, the hand-unrolled form only cost registers)
-    for (int p = p0 + pl; p < p1; p += PL) {
+    auto ld = [&](const void* q, int64_t i, int code) __attribute__((always_inline)) { return st_ld4(q, i, SM == ST_MIXED ? code : SM); };
+    int p = p0 + pl;
+    for (; SM != ST_MIXED && p + (NU - 1) * PL < p1; p += NU * PL) {      // NU pixels' loads in flight, summed in the order of the plain loop (same bits)
+        st_f32x4 xv[NU], gv[NU], yv[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int64_t i = base + (int64_t)(p + u * PL) * C4 + cg;
+            xv[u] = ld(x, i, st.x); gv[u] = ld(dy, i, st.dy); yv[u] = ones;
+        }
+        if (need_y) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) yv[u] = ld(y, base + (int64_t)(p + u * PL) * C4 + cg, st.y);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc(xv[u], gv[u], yv[u]);
+    }
+    for (; p < p1; p += PL) {
         const int64_t i = base + (int64_t)p * C4 + cg;
-        acc(st_ld4(x, i, st.x), st_ld4(dy, i, st.dy), need_y ? st_ld4(y, i, st.y) : ones);
+        acc(ld(x, i, st.x), ld(dy, i, st.dy), need_y ? ld(y, i, st.y) : ones);
     }
     __shared__ float4 r1[256], r2[256];
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
@@ -558,8 +660,17 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
     float* cB = cA + (size_t)B * C;
     float* cC = cB + (size_t)B * C;
     const int pcs = kind != ACLGAN_NORM_LN;
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(nchunks, B), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, part, HW, C, chunk,
-                       nchunks, act, msc, msh);
+    {
+        const bool ry = act != ACLGAN_ACT_NONE && !msc;
+        const int sm = (sd.dy == sd.x && (!ry || sd.y == sd.x)) ? sd.x : ST_MIXED;
+#define ACL_NBR(SM) hipLaunchKernelGGL(norm_bwd_reduce_kernel<SM>, dim3(nchunks, B), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, part, HW, C, chunk, \
+                                       nchunks, act, msc, msh)
+        if (sm == ST_F32) ACL_NBR(ST_F32);
+        else if (sm == ST_BF16) ACL_NBR(ST_BF16);
+        else if (sm == ST_F16) ACL_NBR(ST_F16);
+        else ACL_NBR(ST_MIXED);
+#undef ACL_NBR
+    }
     ACL_CHECK_LAUNCH("norm_bwd_reduce_kernel");
     if (kind == ACLGAN_NORM_LN) {
         ACL_REQUIRE(w, "LN backward needs gamma");
