@@ -679,6 +679,10 @@ int glds_tile(int rows, int N) {
     if (force == 3 && t256) return 3;
     if (force == 2 && t128) return 2;
     if (force == 4) return t256 >= 224 ? 3 : t128 >= 224 ? 2 : 1;      // "largest tile that fills the chip"
+    // default: 128-row tiles -- except on grids of 8+ rounds of them (fp16 at its per-GPU batch 32: 2048 tiles on the 256-channel maps), where the
+    // largest tile that still fills the chip twice wins: fp16 B=32 step 164.3 / 165.8 / 165.9 ms against 166.1 / 166.8 / 167.3 (round 6, same box
+    // back to back); at B=8 (512 tiles) it loses (bf16 46.8 against 46.6 ms)
+    if (force == 0 && N % 128 == 0 && cdiv(rows, 128) * (N / 128) >= 2048) return t256 >= 448 ? 3 : t128 >= 448 ? 2 : 1;
     return 1;
 }
 
