@@ -439,6 +439,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_dgrad_fast_kernel(DgFP pk) 
     }
 }
 
+int halo_split_override();
 template <int WM, int WN, int TM, int TN>
 int launch_dgrad_fast(const ConvGeom& g, DgFP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -465,6 +466,7 @@ int launch_dgrad_fast(const ConvGeom& g, DgFP p, hipStream_t st) {
     const int nk_plan = (p.mode == 2 && p.band == 0) ? std::max(g.Co / 16, nk_min / ((g.k + g.s - 1) / g.s)) : nk_min;
     if (nblk < 128 && nk_plan >= 32 && !deterministic() && !p.ringpad)       // (the slices combine with fp32 atomics; ringpad: one plain store per position)
         p.ksplit = max(1, min(nk_plan / 8, 512 / nblk));   // floor: stay within one round of 512 resident workgroups
+    if (p.mode == 2 && p.band == 0 && !p.ringpad && !deterministic() && halo_split_override() > 0) p.ksplit = std::min(halo_split_override(), nk_plan);
     if (p.ksplit > 1 && p.mode == 0) {
         hipError_t e = hipMemsetAsync(p.dxp, 0, conv_dgrad_scratch_bytes(g), st);
         if (e != hipSuccess) return hip_fail(e, "memset dxp");
@@ -515,6 +517,35 @@ int launch_dgrad_fast_merged(const ConvGeom& g, DgFP p, hipStream_t st) {
     return ACLGAN_OK;
 }
 
+// the halo ring of a reflection-padded layer (mode 2): its GEMM is short and wide (3x3 ResBlock layer at 64x64 B=8: 2 016 ring rows x 256 x 768
+// useful k) and latency-bound -- a single 128 x 128 slice takes 2.7 us per 16-channel k-tile, three times its MFMAs.  Measured on that layer
+// (kernel trace of the operator, scripts/r06/gpu15.sh; tile x split count): 128 x 128: 131 / 74.5 / 54.2 / 45.9 / 38.5 us with 1 / 2 / 3 / 4 / 6
+// slices; 64 x 64: 54.7 (1) / 39.3 (2) / 35.0 (3); 64 x 128: **34.3** (planned: 6) / 36.4 (3); 128 x 64: 35.9 (6) / 38.7 (3).  No shape gets under
+// ~34 us: the ring is a fixed cost of prologue (tap lists), a short dependent loop and the mirrored atomics.  Default: 64 x 128 on the 3x3
+// stride-1 layers (what was measured), the caller's tile elsewhere.  ACLGAN_HALO_TILE = 1 / 2 / 3 forces 64 x 64 / 64 x 128 / 128 x 64 on every
+// layer with Cin % 64 == 0, 4 = the caller's tile everywhere; ACLGAN_HALO_SPLIT overrides the slice count.
+static int halo_tile_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACLGAN_HALO_TILE"); v = e ? atoi(e) : 0; if (v < 0 || v > 4) v = 0; }
+    return v;
+}
+int halo_split_override() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("ACLGAN_HALO_SPLIT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+template <int WM, int WN, int TM, int TN>
+int launch_dgrad_halo(const ConvGeom& g, DgFP p, hipStream_t st) {
+    if (p.band == 0 && !p.ringpad && g.Ci % 64 == 0) {
+        int t = halo_tile_mode();
+        if (t == 0 && g.k == 3 && g.s == 1 && g.Ci % 128 == 0 && WM == 2 && WN == 2 && TM == 2 && TN == 2) t = 2;
+        if (t == 1) return launch_dgrad_fast<2, 2, 1, 1>(g, p, st);       // 64 x 64
+        if (t == 2) return launch_dgrad_fast<2, 2, 1, 2>(g, p, st);       // 64 x 128
+        if (t == 3) return launch_dgrad_fast<2, 2, 2, 1>(g, p, st);       // 128 x 64
+    }
+    return launch_dgrad_fast<WM, WN, TM, TN>(g, p, st);
+}
+
 template <int WM, int WN, int TM, int TN>
 int dgrad_fast_all(const ConvGeom& g, DgFP p, float* dxp, float* dx, int accumulate, bool* direct, hipStream_t st) {
     // deterministic mode: the Winograd layers keep their fast interior and fold the ring in order (below); every other layer
@@ -541,7 +572,7 @@ int dgrad_fast_all(const ConvGeom& g, DgFP p, float* dxp, float* dx, int accumul
             if (rc) return rc;
             return conv_fold(g, dxp, dx, 1, st);
         }
-        if (g.p > 0) { p.mode = 2; rc = launch_dgrad_fast<WM, WN, TM, TN>(g, p, st); }
+        if (g.p > 0) { p.mode = 2; rc = launch_dgrad_halo<WM, WN, TM, TN>(g, p, st); }
         return rc;
     }
     *direct = false;
