@@ -404,6 +404,9 @@ NORM_CASES = [  # (kind, act, B, H, W, C, residual)
     ("ln", "relu", 2, 16, 16, 128, False), ("ln", "relu", 1, 32, 32, 64, False), ("ln", "relu", 3, 6, 10, 8, False),
     ("in", "relu", 2, 64, 64, 64, False),
     ("ln", "relu", 2, 4, 6, 512, False), ("in", "none", 1, 5, 7, 4, False), ("ln", "none", 2, 64, 64, 64, False),   # C > 256 / C = 4 / many chunks
+    # round 6: 512 chunks per sample -- the LayerNorm statistics in 32 slices (stage 2 inside the apply kernel), the division-free InstanceNorm
+    # finalize in two rounds of 16 partials per thread
+    ("ln", "relu", 1, 128, 128, 128, False), ("in", "none", 1, 128, 128, 32, True),
 ]
 
 
