@@ -149,6 +149,7 @@ SIGNATURES = {
     "aclgan_avgpool3s2_bwd": (ci, [ci, ci, ci, ci, vp, vp, ci, vp]),
     "aclgan_adam_flat": (ci, [vp, vp, vp, vp, i64, C.POINTER(Adam), ci, vp]),
     "aclgan_linear_fwd": (ci, [ci, ci, ci, vp, vp, vp, ci, vp, vp]),
+    "aclgan_mlp3_fwd": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "aclgan_linear_bwd": (ci, [ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "aclgan_gap_fwd": (ci, [ci, ci, ci, vp, vp, vp]),
     "aclgan_gap_bwd": (ci, [ci, ci, ci, vp, vp, ci, vp]),

@@ -25,7 +25,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 // scheduler switches (common.h)
-static std::atomic<int> g_lanes{-1}, g_u_batch{-1}, g_norm_mask{-1};
+static std::atomic<int> g_lanes{-1}, g_u_batch{-1}, g_norm_mask{-1}, g_mlp_fused{-1};
 static std::atomic<long long> g_tuning_epoch{0};
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 // (1 .. 3: the updates assign work to lanes 0 .. 2 only; a value of 4 used to be accepted, ran the 3-lane plan and still created a 4th pooled
@@ -36,6 +36,8 @@ int u_batch_setting() { int v = g_u_batch.load(); if (v < 0) { v = env_int("ACLG
 int set_u_batch(int v) { const int old = u_batch_setting(); g_u_batch.store(v ? 1 : 0); return old; }
 int norm_mask_setting() { int v = g_norm_mask.load(); if (v < 0) { v = env_int("ACLGAN_NORM_MASK", 1) ? 1 : 0; g_norm_mask.store(v); } return v; }
 int set_norm_mask(int v) { const int old = norm_mask_setting(); g_norm_mask.store(v ? 1 : 0); return old; }
+int mlp_fused_setting() { int v = g_mlp_fused.load(); if (v < 0) { v = env_int("ACLGAN_MLP_FUSED", 1) ? 1 : 0; g_mlp_fused.store(v); } return v; }
+int set_mlp_fused(int v) { const int old = mlp_fused_setting(); g_mlp_fused.store(v ? 1 : 0); return old; }
 static std::atomic<int> g_fault_at{-1};
 int fault_at_setting() { return g_fault_at.load(); }
 int set_fault_at(int v) { return g_fault_at.exchange(v); }
@@ -280,6 +282,7 @@ int aclgan_tuning(const char* key, int value, int* previous) {
     else if (!strcmp(key, "lanes")) old = set_lanes(value);
     else if (!strcmp(key, "u_batch")) old = set_u_batch(value);
     else if (!strcmp(key, "norm_mask")) old = set_norm_mask(value);
+    else if (!strcmp(key, "mlp_fused")) old = set_mlp_fused(value);
     else if (!strcmp(key, "fault_at")) old = set_fault_at(value);
     else { set_error("aclgan_tuning: unknown key '%s'", key); return ACLGAN_EINVAL; }
     bump_tuning_epoch();
@@ -298,6 +301,7 @@ int aclgan_tuning_get(const char* key, long long* value) {
     else if (!strcmp(key, "lanes")) old = lanes_setting();
     else if (!strcmp(key, "u_batch")) old = u_batch_setting();
     else if (!strcmp(key, "norm_mask")) old = norm_mask_setting();
+    else if (!strcmp(key, "mlp_fused")) old = mlp_fused_setting();
     else if (!strcmp(key, "fault_at")) old = fault_at_setting();
     else { set_error("aclgan_tuning_get: no getter for key '%s'", key); return ACLGAN_EINVAL; }      // (the 16-bit kernel-variant switches are write-only test knobs)
     *value = old;
@@ -364,6 +368,13 @@ int aclgan_norm_bwd_st(int kind, int act, int B, int HW, int C, const void* x, c
 int aclgan_linear_fwd(int B, int I, int O, const float* x, const float* w, const float* bias, int act, float* y, void* stream) {
     ACL_REQUIRE(B > 0 && I > 0 && O > 0 && x && w && y, "linear_fwd: bad arguments");
     return linear_fwd(B, I, O, x, w, bias, act, y, (hipStream_t)stream);
+}
+int aclgan_mlp3_fwd(int B, int S, int M, int O, const float* s, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* m0, float* m1, float* ap, void* stream) {
+    ACL_REQUIRE(B > 0 && S > 0 && M > 0 && O > 0 && s && w0 && w1 && w2 && m0 && m1 && ap, "mlp3_fwd: bad arguments");
+    const int rc = mlp3_fwd(B, S, M, O, s, w0, b0, w1, b1, w2, b2, m0, m1, ap, (hipStream_t)stream);
+    if (rc == ACLGAN_EUNSUPPORTED) set_error("mlp3_fwd: style width %d / hidden width %d outside the fused kernel's range (S <= 64, M in {64, 128, 192, 256})", S, M);
+    return rc;
 }
 int aclgan_linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, const float* w, int act, float* dx, float* dw, float* db,
                       void* stream) {

@@ -49,6 +49,9 @@ int set_u_batch(int v);
 //   norm_mask (ACLGAN_NORM_MASK, default 1): the norm backward recomputes ReLU masks from x and the forward's coefficients instead of reading y
 int norm_mask_setting();
 int set_norm_mask(int v);
+//   mlp_fused (ACLGAN_MLP_FUSED, default 1): the generator's MLP forward as one launch (misc.hip: mlp3_fwd) instead of three linear_fwd launches
+int mlp_fused_setting();
+int set_mlp_fused(int v);
 //   fault_at (test hook, default -1 = off): the backward replay fails with ACLGAN_EHIP after its fault_at-th closure has been enqueued --
 //   the error path (lanes and side stream drained before the caller is told) is testable without breaking the GPU
 int fault_at_setting();
@@ -257,6 +260,10 @@ int fill_zero(float* p, int64_t n, hipStream_t st);
 
 // small dense layers (MLP, style head): y[b][o] = act(sum_i x[b][i] W[o][i] + bias[o])
 int linear_fwd(int B, int I, int O, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st);
+// the generator's three-layer MLP forward in one launch (misc.hip: bit-identical to three linear_fwd calls); EUNSUPPORTED outside S <= 64, M in {64, 128, 192, 256}
+bool mlp3_fwd_ok(int S, int M);
+int mlp3_fwd(int B, int S, int M, int O, const float* s, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+             const float* b2, float* m0, float* m1, float* ap, hipStream_t st);
 // dy is modified in place by the activation backward; dx overwritten (may be null); dw,db accumulate
 int linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, const float* w, int act,
                float* dx, float* dw, float* db, hipStream_t st);

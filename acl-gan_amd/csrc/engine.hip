@@ -997,15 +997,16 @@ static int content_encode(aclgan_ctx& c, int net, bool train, Act* x, Act** out)
     return ACLGAN_OK;
 }
 
-// dense layer with tape
-static int dense(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int O, int act, Act** out_p) {
+// dense layer with tape (launch = false: the caller runs the forward itself -- the fused MLP launch of decode() -- and this call only
+// allocates the output, accounts for it and records the backward)
+static int dense(aclgan_ctx& c, const PW& W, bool train_w, Act* in, int O, int act, Act** out_p, bool launch = true) {
     const int B = in->B, I = in->H * in->W * in->C;
     const bool want = train_w || in->need_grad;
     CHK(c.need(in));
     Act* out = c.new_act(B, 1, 1, O, want);
     NEED(out->d); if (want) NEED(out->g);
     if (!W.w) { set_error("dense: parameters not bound"); return ACLGAN_EINVAL; }
-    RUN(linear_fwd(B, I, O, in->d, W.w, W.b, act, out->d, c.st));
+    if (launch) RUN(linear_fwd(B, I, O, in->d, W.w, W.b, act, out->d, c.st));
     c.count(4.0 * ((double)B * I + (double)O * I + O + (double)B * O) * (want ? 3.0 : 1.0));    // (+ backward: the same operands again, twice)
     c.wrote(out);
     *out_p = out;
@@ -1092,9 +1093,15 @@ static int decode(aclgan_ctx& c, int net, bool train, Act* content, Act* style, 
     const int C = content->C, nr = a.gen_n_res, nad = 2 * C * 2 * nr;
     // MLP (networks.py:280-292)
     Act *m0 = nullptr, *m1 = nullptr, *ap = nullptr;
-    CHK(dense(c, c.pw(0, net, "mlp.model.0.fc"), train, style, a.gen_mlp_dim, ACLGAN_ACT_RELU, &m0));
-    CHK(dense(c, c.pw(0, net, "mlp.model.1.fc"), train, m0, a.gen_mlp_dim, ACLGAN_ACT_RELU, &m1));
-    CHK(dense(c, c.pw(0, net, "mlp.model.2.fc"), train, m1, nad, ACLGAN_ACT_NONE, &ap));
+    // (round 6) one launch for the three layers where the widths allow (misc.hip: mlp3_fwd -- the same bits as three linear_fwd launches);
+    // activations, accounting and the three backward closures are those of dense()
+    const int sdim = style->H * style->W * style->C;
+    const bool fused = mlp_fused_setting() && mlp3_fwd_ok(sdim, a.gen_mlp_dim);
+    const PW W0 = c.pw(0, net, "mlp.model.0.fc"), W1 = c.pw(0, net, "mlp.model.1.fc"), W2 = c.pw(0, net, "mlp.model.2.fc");
+    CHK(dense(c, W0, train, style, a.gen_mlp_dim, ACLGAN_ACT_RELU, &m0, !fused));
+    CHK(dense(c, W1, train, m0, a.gen_mlp_dim, ACLGAN_ACT_RELU, &m1, !fused));
+    CHK(dense(c, W2, train, m1, nad, ACLGAN_ACT_NONE, &ap, !fused));
+    if (fused) RUN(mlp3_fwd(style->B, sdim, a.gen_mlp_dim, nad, style->d, W0.w, W0.b, W1.w, W1.b, W2.w, W2.b, m0->d, m1->d, ap->d, c.st));
     if (ap->need_grad) {   // AdaIN layers accumulate dw/db into disjoint column slices
         RUN(fill_zero(ap->g, ap->numel(), c.st));
         mark_written(ap);

@@ -331,6 +331,96 @@ int linear_fwd(int B, int I, int O, const float* x, const float* w, const float*
     ACL_CHECK_LAUNCH("linear_fwd_kernel");
     return ACLGAN_OK;
 }
+// ---- the generator's MLP (networks.py:280-292: Linear + ReLU, Linear + ReLU, Linear) forward as ONE launch (round 6) ----
+// style [B][S] -> m0 = relu(W0 s + b0) [B][M] -> m1 = relu(W1 m0 + b1) [B][M] -> ap = W2 m1 + b2 [B][O]  (S <= 64, M = 64 MK <= 256).
+// Every workgroup recomputes layers 1 and 2 (0.5 M multiply-adds at B = 8, M = 256: ~3 us) and produces `per` outputs of layer 3; workgroup 0
+// also stores m0 and m1 (the backward reads them).  Arithmetic per output = linear_fwd_kernel's, bit for bit: a wave per output feature, lane l
+// multiplies inputs l, l + 64, ... in that order, the 64 partial sums are combined along the same xor-butterfly tree (32, 16, 8, 4, 2, 1) --
+// here as a transpose-reduce over the 8 batch rows (10 shuffles per output instead of 48: each halving step also halves the rows a lane keeps).
+__device__ __forceinline__ float rows8_reduce(const float (&v)[8], int lane, int& row) {
+    const bool hi = lane & 32, mid = lane & 16, q = lane & 8;
+    float t[4], u[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = (hi ? v[j + 4] : v[j]) + __shfl_xor(hi ? v[j] : v[j + 4], 32);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) u[j] = (mid ? t[j + 2] : t[j]) + __shfl_xor(mid ? t[j] : t[j + 2], 16);
+    float w = (q ? u[1] : u[0]) + __shfl_xor(q ? u[0] : u[1], 8);
+    w += __shfl_xor(w, 4); w += __shfl_xor(w, 2); w += __shfl_xor(w, 1);
+    row = (hi ? 4 : 0) + (mid ? 2 : 0) + (q ? 1 : 0);
+    return w;
+}
+// one dense layer of the fused kernel: outputs [o0, o1) of  y[r][o] = act(sum_i x[r][i] W[o][i] + bias[o]),  x in registers (xr[r][k] = x[r][lane + 64 k])
+template <int K, class Store>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ W, const float* __restrict__ bias, int I, int o0, int o1, const float (&xr)[8][K],
+                                          int lane, int wave, int act, Store store) {
+    for (int o = o0 + wave; o < o1; o += 4) {
+        float wv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const int i = lane + 64 * k; wv[k] = i < I ? W[(size_t)o * I + i] : 0.f; }
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            acc[r] = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (lane + 64 * k < I) acc[r] = fmaf(xr[r][k], wv[k], acc[r]);
+        }
+        int row;
+        const float tot = rows8_reduce(acc, lane, row);
+        if ((lane & 7) == 0) store(row, o, act_fwd_m(tot + (bias ? bias[o] : 0.f), act));
+    }
+}
+template <int MK>
+__global__ void __launch_bounds__(256) mlp3_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                                       const float* __restrict__ b2, float* __restrict__ m0, float* __restrict__ m1,
+                                                       float* __restrict__ ap, int B, int S, int O, int per) {
+    constexpr int M = 64 * MK;
+    __shared__ float sh_a[8][M], sh_b[8][M];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o0 = blockIdx.x * per, o1 = min(O, o0 + per);
+    for (int r0 = 0; r0 < B; r0 += 8) {
+        const int nb = min(8, B - r0);
+        __syncthreads();                                   // the previous pass has read sh_a / sh_b
+        float x1[8][1];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x1[r][0] = (r < nb && lane < S) ? s[(size_t)(r0 + r) * S + lane] : 0.f;
+        mlp_layer<1>(W0, b0, S, 0, M, x1, lane, wave, ACLGAN_ACT_RELU, [&](int r, int o, float v) {
+            sh_a[r][o] = v;
+            if (blockIdx.x == 0 && r < nb) m0[(size_t)(r0 + r) * M + o] = v;
+        });
+        __syncthreads();
+        float xr[8][MK];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int k = 0; k < MK; ++k) xr[r][k] = sh_a[r][lane + 64 * k];
+        mlp_layer<MK>(W1, b1, M, 0, M, xr, lane, wave, ACLGAN_ACT_RELU, [&](int r, int o, float v) {
+            sh_b[r][o] = v;
+            if (blockIdx.x == 0 && r < nb) m1[(size_t)(r0 + r) * M + o] = v;
+        });
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int k = 0; k < MK; ++k) xr[r][k] = sh_b[r][lane + 64 * k];
+        mlp_layer<MK>(W2, b2, M, o0, o1, xr, lane, wave, ACLGAN_ACT_NONE, [&](int r, int o, float v) {
+            if (r < nb) ap[(size_t)(r0 + r) * O + o] = v;
+        });
+    }
+}
+bool mlp3_fwd_ok(int S, int M) { return S >= 1 && S <= 64 && M % 64 == 0 && M >= 64 && M <= 256; }
+int mlp3_fwd(int B, int S, int M, int O, const float* s, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+             const float* b2, float* m0, float* m1, float* ap, hipStream_t st) {
+    if (!mlp3_fwd_ok(S, M)) return ACLGAN_EUNSUPPORTED;
+    const int per = O >= 2048 ? 64 : std::max(4, cdiv(O, 32));      // (64 workgroups on the 4096-wide AdaIN head)
+    const dim3 grid(cdiv(O, per));
+#define ACL_MLP3(MK) hipLaunchKernelGGL(mlp3_fwd_kernel<MK>, grid, dim3(256), 0, st, s, W0, b0, W1, b1, W2, b2, m0, m1, ap, B, S, O, per)
+    if (M == 64) ACL_MLP3(1); else if (M == 128) ACL_MLP3(2); else if (M == 192) ACL_MLP3(3); else ACL_MLP3(4);
+#undef ACL_MLP3
+    ACL_CHECK_LAUNCH("mlp3_fwd_kernel");
+    return ACLGAN_OK;
+}
 __global__ void linear_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                  float* __restrict__ db, int B, int I, int O) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;

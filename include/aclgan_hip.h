@@ -358,7 +358,9 @@ int aclgan_conv2d_fwd16s(const aclgan_conv_desc* d, int dtype, const void* x16, 
  * 1 = one queue (the round-4 plan), default 3 (ACLGAN_LANES).  Results do not depend on it.  key "u_batch" (round 5): 1 (default) =
  * the Winograd transforms of all ResBlock filters of a network are one launch at the start of an update, 0 = one launch per filter at
  * its first use.  key "norm_mask" (round 5): 1 (default) = the backward of an activated normalisation layer recomputes the ReLU mask from x and
- * the forward's fused coefficients instead of reading y back (same mask: the same fmaf), 0 = reads y.  key "fault_at" (test hook; -1 = off): the backward replay of the next updates fails with ACLGAN_EHIP after that many
+ * the forward's fused coefficients instead of reading y back (same mask: the same fmaf), 0 = reads y.  key "mlp_fused" (round 6): 1 (default) = the
+ * generator's MLP forward (networks.py:280-292) is one launch (aclgan_mlp3_fwd), 0 = three aclgan_linear_fwd launches; the same bits either way.
+ * key "fault_at" (test hook; -1 = off): the backward replay of the next updates fails with ACLGAN_EHIP after that many
  * closures have been enqueued -- exercises the error path (all internal streams drained before the call returns).
  * Returns the previous value, -1 for an unknown key.  The switches are atomics (a concurrent update sees the old or the new value, never a
  * torn one), but changing one WHILE an update is being enqueued changes that update's plan half way: do not. */
@@ -366,7 +368,7 @@ int aclgan_set_tuning(const char* key, int value);
 /* The same switches with the status in the return value (round 5): ACLGAN_OK and the previous setting through *previous (may be NULL), or
  * ACLGAN_EINVAL for an unknown key (aclgan_set_tuning cannot tell -1 "unknown" from a previous value). */
 int aclgan_tuning(const char* key, int value, int* previous);
-/* Read a switch without touching it (round 6; no state change, no tuning-epoch bump): keys "lanes", "u_batch", "norm_mask", "wino_fused",
+/* Read a switch without touching it (round 6; no state change, no tuning-epoch bump): keys "lanes", "u_batch", "norm_mask", "mlp_fused", "wino_fused",
  * "wino_wgrad_fused", "wino_s2k4", "fault_at", and "epoch" = the number of aclgan_tuning calls so far (cached switch-dependent results -- an arena
  * size -- are valid for one epoch).  ACLGAN_EINVAL for any other key. */
 int aclgan_tuning_get(const char* key, long long* value);
@@ -442,6 +444,12 @@ int aclgan_avgpool3s2_bwd(int B, int H, int W, int C, const float* dy, float* dx
 int aclgan_linear_fwd(int B, int I, int O, const float* x, const float* w, const float* bias, int act, float* y, void* stream);
 int aclgan_linear_bwd(int B, int I, int O, const float* x, const float* y, float* dy, const float* w, int act,
                       float* dx, float* dw, float* db, void* stream);
+/* MLP.forward (networks.py:280-292; AdaINGen.decode's style -> AdaIN parameters, networks.py:147-151) as ONE launch:
+ * m0 = relu(w0 s + b0) [B][M], m1 = relu(w1 m0 + b1) [B][M], ap = w2 m1 + b2 [B][O]; s is [B][S].  Bit-identical to three aclgan_linear_fwd
+ * calls (same per-lane order, same reduction tree).  ACLGAN_EUNSUPPORTED outside S <= 64, M in {64, 128, 192, 256} (the engine then runs
+ * the three launches).  The backward stays aclgan_linear_bwd per layer on m0 / m1 / ap. */
+int aclgan_mlp3_fwd(int B, int S, int M, int O, const float* s, const float* w0, const float* b0, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* m0, float* m1, float* ap, void* stream);
 /* AdaptiveAvgPool2d(1) (networks.py:222), NHWC [B][HW][C] -> [B][C] */
 int aclgan_gap_fwd(int B, int HW, int C, const float* x, float* y, void* stream);
 int aclgan_gap_bwd(int B, int HW, int C, const float* dy, float* dx, int accumulate, void* stream);

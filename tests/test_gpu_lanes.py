@@ -122,6 +122,29 @@ def test_batched_filter_transforms_same_bits_fewer_launches(L):
     assert (n1 - n0) - (n2 - n1) >= 60, (n1 - n0, n2 - n1)
 
 
+def test_fused_mlp_forward_same_bits_fewer_launches(L):
+    """round 6: the generator's MLP forward as one launch (aclgan_mlp3_fwd) against three aclgan_linear_fwd launches: the same bits in every loss,
+    gradient and parameter of a step, 2 launches fewer per decode"""
+    from aclgan_amd import trainer as T
+    from test_gpu_determinism import _step
+    cfg, nets, x_a, x_b, z = _fixture()
+    prev_det = L.lib.aclgan_get_deterministic()
+    prev = _tune(L, b"mlp_fused", 0)
+    try:
+        n0 = L.lib.aclgan_launch_count()
+        three = _step(T, cfg, nets, x_a, x_b, z, "fp32", True)
+        n1 = L.lib.aclgan_launch_count()
+        _tune(L, b"mlp_fused", 1)
+        one = _step(T, cfg, nets, x_a, x_b, z, "fp32", True)
+        n2 = L.lib.aclgan_launch_count()
+    finally:
+        _tune(L, b"mlp_fused", prev)
+        L.check(L.lib.aclgan_set_deterministic(prev_det))
+    _same(three, one)
+    print("launches of (dis_update + gen_update): three-launch MLP %d, fused %d" % (n1 - n0, n2 - n1))
+    assert (n1 - n0) - (n2 - n1) >= 16, (n1 - n0, n2 - n1)      # (4 decodes in dis_update + 5 in gen_update, 2 launches each)
+
+
 def test_lsgan_batch_equals_the_operator(L):
     """One launch for all (scale, segment) terms of a discriminator call (aclgan_lsgan_loss_multi = the engine's lsgan_loss_batch;
     networks.py:64-67,81-83,96-98) against the per-term operator: loss slots and loss gradients bit for bit, including several terms

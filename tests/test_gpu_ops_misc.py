@@ -69,6 +69,36 @@ def test_linear_fwd_bwd(L, B, I, Oo, act):
     assert rel_err(dw, 2 * w.grad) < TOL and rel_err(db, 2 * b.grad) < TOL
 
 
+@pytest.mark.parametrize("B,S,M,Oo", [(8, 8, 256, 4096), (3, 8, 256, 4096), (11, 8, 64, 100), (1, 64, 128, 7), (16, 5, 192, 2048)])
+def test_mlp3_fwd_is_three_linear_fwd(L, B, S, M, Oo):
+    """MLP.forward (networks.py:280-292) in one launch: bit-identical to three aclgan_linear_fwd calls (and those are checked against
+    F.linear above); batches beyond 8 rows, style widths up to 64, ragged output counts"""
+    g = torch.Generator().manual_seed(9)
+    s = torch.randn(B, S, generator=g).cuda()
+    w0 = (torch.randn(M, S, generator=g) * (2.0 / S) ** 0.5).cuda(); b0 = (torch.randn(M, generator=g) * 0.1).cuda()
+    w1 = (torch.randn(M, M, generator=g) * (2.0 / M) ** 0.5).cuda(); b1 = (torch.randn(M, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(Oo, M, generator=g) * (2.0 / M) ** 0.5).cuda(); b2 = (torch.randn(Oo, generator=g) * 0.1).cuda()
+    r0 = torch.empty(B, M, device="cuda"); r1 = torch.empty(B, M, device="cuda"); r2 = torch.empty(B, Oo, device="cuda")
+    st = L.stream_ptr()
+    L.check(L.lib.aclgan_linear_fwd(B, S, M, L.ptr(s), L.ptr(w0), L.ptr(b0), L.ACT["relu"], L.ptr(r0), st))
+    L.check(L.lib.aclgan_linear_fwd(B, M, M, L.ptr(r0), L.ptr(w1), L.ptr(b1), L.ACT["relu"], L.ptr(r1), st))
+    L.check(L.lib.aclgan_linear_fwd(B, M, Oo, L.ptr(r1), L.ptr(w2), L.ptr(b2), L.ACT["none"], L.ptr(r2), st))
+    m0 = torch.full((B, M), float("nan"), device="cuda"); m1 = torch.full((B, M), float("nan"), device="cuda")
+    ap = torch.full((B, Oo), float("nan"), device="cuda")
+    L.check(L.lib.aclgan_mlp3_fwd(B, S, M, Oo, L.ptr(s), L.ptr(w0), L.ptr(b0), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(m0), L.ptr(m1),
+                                  L.ptr(ap), st), "mlp3_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(m0, r0) and torch.equal(m1, r1) and torch.equal(ap, r2)
+    ref = F.linear(F.relu(F.linear(F.relu(F.linear(s.cpu(), w0.cpu(), b0.cpu())), w1.cpu(), b1.cpu())), w2.cpu(), b2.cpu())
+    assert ((ap.cpu() - ref).abs().max() / ref.abs().max()).item() < TOL
+
+
+def test_mlp3_fwd_refuses_widths_it_does_not_cover(L):
+    z = torch.zeros(8 * 512, device="cuda")
+    rc = L.lib.aclgan_mlp3_fwd(1, 8, 512, 8, L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.stream_ptr())
+    assert rc == -2, rc      # ACLGAN_EUNSUPPORTED: the engine then runs the three launches
+
+
 @pytest.mark.parametrize("B,HW,Cn", [(8, 256, 256), (2, 16, 64), (3, 35, 8), (1, 1, 16)])
 def test_gap_fwd_bwd(L, B, HW, Cn):
     from gpu_util import rel_err
