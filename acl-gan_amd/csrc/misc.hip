@@ -333,7 +333,7 @@ int linear_fwd(int B, int I, int O, const float* x, const float* w, const float*
 }
 // ---- the generator's MLP (networks.py:280-292: Linear + ReLU, Linear + ReLU, Linear) forward as ONE launch (round 6) ----
 // style [B][S] -> m0 = relu(W0 s + b0) [B][M] -> m1 = relu(W1 m0 + b1) [B][M] -> ap = W2 m1 + b2 [B][O]  (S <= 64, M = 64 MK <= 256).
-// Every workgroup recomputes layers 1 and 2 (0.5 M multiply-adds at B = 8, M = 256: ~3 us) and produces `per` outputs of layer 3; workgroup 0
+// Every workgroup (16 waves) recomputes layers 1 and 2 (0.5 M multiply-adds at B = 8, M = 256) and produces `per` outputs of layer 3; workgroup 0
 // also stores m0 and m1 (the backward reads them).  Arithmetic per output = linear_fwd_kernel's, bit for bit: a wave per output feature, lane l
 // multiplies inputs l, l + 64, ... in that order, the 64 partial sums are combined along the same xor-butterfly tree (32, 16, 8, 4, 2, 1) --
 // here as a transpose-reduce over the 8 batch rows (10 shuffles per output instead of 48: each halving step also halves the rows a lane keeps).
@@ -349,32 +349,47 @@ __device__ __forceinline__ float rows8_reduce(const float (&v)[8], int lane, int
     row = (hi ? 4 : 0) + (mid ? 2 : 0) + (q ? 1 : 0);
     return w;
 }
-// one dense layer of the fused kernel: outputs [o0, o1) of  y[r][o] = act(sum_i x[r][i] W[o][i] + bias[o]),  x in registers (xr[r][k] = x[r][lane + 64 k])
+// one dense layer of the fused kernel: outputs [o0, o1) of  y[r][o] = act(sum_i x[r][i] W[o][i] + bias[o]),  x in registers (xr[r][k] = x[r][lane + 64 k]).
+// A wave takes MLP_U outputs per iteration (their weight loads and reduction chains are independent: one load latency and one shuffle chain per
+// iteration, not per output -- the first version, one output per iteration and 4 waves, spent 113 us per launch waiting: 64 dependent iterations).
+constexpr int MLP_NW = 16, MLP_U = 4;
 template <int K, class Store>
 __device__ __forceinline__ void mlp_layer(const float* __restrict__ W, const float* __restrict__ bias, int I, int o0, int o1, const float (&xr)[8][K],
                                           int lane, int wave, int act, Store store) {
-    for (int o = o0 + wave; o < o1; o += 4) {
-        float wv[K];
+    for (int ob = o0 + wave * MLP_U; ob < o1; ob += MLP_NW * MLP_U) {
+        float wv[MLP_U][K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) { const int i = lane + 64 * k; wv[k] = i < I ? W[(size_t)o * I + i] : 0.f; }
-        float acc[8];
+        for (int u = 0; u < MLP_U; ++u) {
+            const int o = min(ob + u, o1 - 1);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            acc[r] = 0.f;
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (lane + 64 * k < I) acc[r] = fmaf(xr[r][k], wv[k], acc[r]);
+            for (int k = 0; k < K; ++k) { const int i = lane + 64 * k; wv[u][k] = i < I ? W[(size_t)o * I + i] : 0.f; }
         }
-        int row;
-        const float tot = rows8_reduce(acc, lane, row);
-        if ((lane & 7) == 0) store(row, o, act_fwd_m(tot + (bias ? bias[o] : 0.f), act));
+        float tot[MLP_U];
+        int row = 0;
+#pragma unroll
+        for (int u = 0; u < MLP_U; ++u) {
+            float acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (lane + 64 * k < I) acc[r] = fmaf(xr[r][k], wv[u][k], acc[r]);
+            }
+            tot[u] = rows8_reduce(acc, lane, row);
+        }
+        if ((lane & 7) == 0) {
+#pragma unroll
+            for (int u = 0; u < MLP_U; ++u)
+                if (ob + u < o1) store(row, ob + u, act_fwd_m(tot[u] + (bias ? bias[ob + u] : 0.f), act));
+        }
     }
 }
 template <int MK>
-__global__ void __launch_bounds__(256) mlp3_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W0, const float* __restrict__ b0,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-                                                       const float* __restrict__ b2, float* __restrict__ m0, float* __restrict__ m1,
-                                                       float* __restrict__ ap, int B, int S, int O, int per) {
+__global__ void __launch_bounds__(MLP_NW * 64) mlp3_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                               const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                                               const float* __restrict__ b2, float* __restrict__ m0, float* __restrict__ m1,
+                                                               float* __restrict__ ap, int B, int S, int O, int per) {
     constexpr int M = 64 * MK;
     __shared__ float sh_a[8][M], sh_b[8][M];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -415,7 +430,7 @@ int mlp3_fwd(int B, int S, int M, int O, const float* s, const float* W0, const 
     if (!mlp3_fwd_ok(S, M)) return ACLGAN_EUNSUPPORTED;
     const int per = O >= 2048 ? 64 : std::max(4, cdiv(O, 32));      // (64 workgroups on the 4096-wide AdaIN head)
     const dim3 grid(cdiv(O, per));
-#define ACL_MLP3(MK) hipLaunchKernelGGL(mlp3_fwd_kernel<MK>, grid, dim3(256), 0, st, s, W0, b0, W1, b1, W2, b2, m0, m1, ap, B, S, O, per)
+#define ACL_MLP3(MK) hipLaunchKernelGGL(mlp3_fwd_kernel<MK>, grid, dim3(MLP_NW * 64), 0, st, s, W0, b0, W1, b1, W2, b2, m0, m1, ap, B, S, O, per)
     if (M == 64) ACL_MLP3(1); else if (M == 128) ACL_MLP3(2); else if (M == 192) ACL_MLP3(3); else ACL_MLP3(4);
 #undef ACL_MLP3
     ACL_CHECK_LAUNCH("mlp3_fwd_kernel");
