@@ -69,12 +69,30 @@ static int norm_chunk_pixels(int B, int HW) {
     return c;
 }
 
-// Storage template parameter of the streaming kernels below: SM = the storage code every operand shares (ST_F32 / ST_BF16 / ST_F16: the switch
-// of st16.h is compiled out), or ST_MIXED = per-operand run-time codes.  Only the compiled-in forms keep NU loads per operand in flight: with
-// run-time codes every load sits in its own branch and is waited for at the branch's end, so unrolling buys registers and nothing else
-// (measured, round 6: the hand-unrolled reduce with run-time codes was 6 .. 19 % SLOWER than the plain loop).
+// Storage template parameters of the streaming kernels below: the storage codes of the operands (ST_F32 / ST_BF16 / ST_F16) compiled in -- one
+// code, or a pair (the layers at the 16-bit / fp32 boundary: x fp32 and y 16-bit, dy fp32 and x 16-bit ...) -- or ST_MIXED = per-operand
+// run-time codes.  NU loads per operand are kept in flight.  With run-time codes that takes st_ld4n (the switch ONCE around an operand's NU
+// loads) and still waits operand by operand (measured at fp16 B=32: 141 us against 70 for the compiled-in pair); a switch around every single
+// load is waited for at its end, and unrolling buys registers and nothing else (the hand-unrolled reduce with per-load switches was 6 .. 19 %
+// SLOWER than the plain loop).
 constexpr int NU = 4;
 constexpr int ST_MIXED = 3;
+// kernels with TWO compiled-in storage codes (e.g. x | everything else): the pairs that occur -- equal codes, and fp32 on one side of the 16-bit /
+// fp32 boundary (the thin image-side layers compute and store fp32, their wide neighbours store the 16-bit compute dtype).  -1: run-time codes.
+static inline int st_pair(int a, int b) { return (a == b || a == ST_F32 || b == ST_F32) ? a * 3 + b : -1; }
+#define ACL_ST_PAIR_DISPATCH(pair, LAUNCH)                                            \
+    do {                                                                              \
+        switch (pair) {                                                               \
+            case 0: LAUNCH(ST_F32, ST_F32); break;                                    \
+            case 1: LAUNCH(ST_F32, ST_BF16); break;                                   \
+            case 2: LAUNCH(ST_F32, ST_F16); break;                                    \
+            case 3: LAUNCH(ST_BF16, ST_F32); break;                                   \
+            case 4: LAUNCH(ST_BF16, ST_BF16); break;                                  \
+            case 6: LAUNCH(ST_F16, ST_F32); break;                                    \
+            case 8: LAUNCH(ST_F16, ST_F16); break;                                    \
+            default: LAUNCH(ST_MIXED, ST_MIXED); break;                               \
+        }                                                                             \
+    } while (0)
 
 // partial statistics: part[b][chunk][c] = (mean, M2) over the chunk's pixels.  Threads are laid
 // out C/4 float4-lanes wide (coalesced 16 B/lane along the channel axis), 256/(C/4) pixels deep.
@@ -96,10 +114,9 @@ __global__ void __launch_bounds__(256) norm_stats_kernel(const void* __restrict_
         q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
     };
     int p = p0 + pl;
-    for (; SM != ST_MIXED && p + (NU - 1) * PL < p1; p += NU * PL) {      // NU loads in flight, added in the order of the plain loop (same bits)
+    for (; p + (NU - 1) * PL < p1; p += NU * PL) {      // NU loads in flight, added in the order of the plain loop (same bits)
         st_f32x4 v[NU];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) v[u] = st_ld4(x, xb + (int64_t)(p + u * PL) * C4 + cg, xst);
+        st_ld4n<NU>(x, xb + (int64_t)p * C4 + cg, (int64_t)PL * C4, xst, v);
 #pragma unroll
         for (int u = 0; u < NU; ++u) acc(v[u]);
     }
@@ -266,12 +283,12 @@ __device__ __forceinline__ void ln_totals(const float4* __restrict__ lnpart, int
 // the grid stride are multiples of C/4 (a power of two <= 256), so a thread's channel quad -- and its eight coefficients -- are fixed:
 // loaded once.  NU float4 per operand in flight per thread.  (Round 6: the previous form -- one flat 64-bit index, i % C4 and
 // i / (HW * C4) per float4, one float4 per thread -- spent more issue slots on the two divisions than on the element and ran at 3.5 TB/s.)
-// SM: the storage code every operand shares (ST_F32 / ST_BF16 / ST_F16: the storage switch of st16.h is compiled out), or ST_MIXED = per-operand
-// run-time codes -- that form keeps one float4 in flight (unrolled, its branches cost more registers and issue slots than the loads win).
+// SX | SY: the storage codes of x | of y and the residual, compiled in (the uniform triples and the fp32 <-> 16-bit boundary pairs: st_pair), or
+// ST_MIXED = per-operand run-time codes -- there the switch is taken once per operand around its NU loads (st_ld4n).
 // LN = true: scale / shift are OUTPUTS -- the workgroup derives them from the sample's LayerNorm triples (ln_totals) and gamma / beta, and
 // workgroup 0 of the sample stores them with mean / rstd for the backward.
 struct LnArgs { const float4* part; int S; const float* gamma; const float* beta; float* mean_o; float* rstd_o; };
-template <int SM, bool LN>
+template <int SX, int SY, bool LN>      // storage of x | of y and the residual (SX == ST_MIXED: run-time codes for all three)
 __global__ void __launch_bounds__(256) norm_apply_kernel(const void* __restrict__ x, float* __restrict__ scale,
                                                          float* __restrict__ shift, const void* __restrict__ res,
                                                          void* __restrict__ y, NormST st, int per4, int C, int act, LnArgs ln) {
@@ -294,23 +311,20 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const void* __restrict_
     }
     const int64_t base = (int64_t)b * per4;
     const int stride = gridDim.x * 256;
-    auto ld = [&](const void* p, int64_t i, int code) __attribute__((always_inline)) { return st_ld4(p, i, SM == ST_MIXED ? code : SM); };
+    constexpr bool RT = SX == ST_MIXED;
+    const int cx = RT ? st.x : SX, cy = RT ? st.y : SY, cr = RT ? st.res : SY;
     auto one = [&](st_f32x4 v) __attribute__((always_inline)) {
         st_f32x4 r;
         r.x = act_fwd(fmaf(v.x, sc.x, sh.x), act); r.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
         r.z = act_fwd(fmaf(v.z, sc.z, sh.z), act); r.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
         return r;
     };
-    auto put = [&](int64_t i, st_f32x4 v) __attribute__((always_inline)) { st_st4(y, i, v, SM == ST_MIXED ? st.y : SM); };
+    auto put = [&](int64_t i, st_f32x4 v) __attribute__((always_inline)) { st_st4(y, i, v, cy); };
     int i = blockIdx.x * 256 + threadIdx.x;
-    for (; SM != ST_MIXED && i + (NU - 1) * stride < per4; i += NU * stride) {
+    for (; i + (NU - 1) * stride < per4; i += NU * stride) {
         st_f32x4 v[NU], r[NU];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) v[u] = ld(x, base + i + u * stride, st.x);
-        if (res) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u) r[u] = ld(res, base + i + u * stride, st.res);
-        }
+        st_ld4n<NU>(x, base + i, stride, cx, v);
+        if (res) st_ld4n<NU>(res, base + i, stride, cr, r);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             st_f32x4 q = one(v[u]);
@@ -319,8 +333,8 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const void* __restrict_
         }
     }
     for (; i < per4; i += stride) {
-        st_f32x4 q = one(ld(x, base + i, st.x));
-        if (res) q += ld(res, base + i, st.res);
+        st_f32x4 q = one(st_ld4(x, base + i, cx));
+        if (res) q += st_ld4(res, base + i, cr);
         put(base + i, q);
     }
 }
@@ -380,13 +394,11 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float
     ACL_REQUIRE((int64_t)HW * (C / 4) < 0x7fffff00ll, "norm: %d pixels x %d channels per sample", HW, C);
     const int per4 = HW * (C / 4);
     const dim3 grid(rows_grid(per4, B), B);
-    const int sm = (sd.x == sd.y && (!residual || sd.res == sd.x)) ? sd.x : ST_MIXED;
-#define ACL_NA(SM, LN) hipLaunchKernelGGL((norm_apply_kernel<SM, LN>), grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act, ln)
-    if (kind == ACLGAN_NORM_LN) {
-        if (sm == ST_F32) ACL_NA(ST_F32, true); else if (sm == ST_BF16) ACL_NA(ST_BF16, true); else if (sm == ST_F16) ACL_NA(ST_F16, true); else ACL_NA(ST_MIXED, true);
-    } else {
-        if (sm == ST_F32) ACL_NA(ST_F32, false); else if (sm == ST_BF16) ACL_NA(ST_BF16, false); else if (sm == ST_F16) ACL_NA(ST_F16, false); else ACL_NA(ST_MIXED, false);
-    }
+    // storage pair (x | y, residual): the uniform triples and the fp32 <-> 16-bit boundary pairs are compiled in, anything else takes run-time codes
+    const int pair = (!residual || sd.res == sd.y) ? st_pair(sd.x, sd.y) : -1;
+#define ACL_NA(SX, SY) do { if (kind == ACLGAN_NORM_LN) hipLaunchKernelGGL((norm_apply_kernel<SX, SY, true>), grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act, ln); \
+                            else hipLaunchKernelGGL((norm_apply_kernel<SX, SY, false>), grid, dim3(256), 0, st, x, scale, shift, residual, y, sd, per4, C, act, ln); } while (0)
+    ACL_ST_PAIR_DISPATCH(pair, ACL_NA);
 #undef ACL_NA
     ACL_CHECK_LAUNCH("norm_apply_kernel");
     return ACLGAN_OK;
@@ -402,7 +414,7 @@ int norm_fwd(int kind, int act, int B, int HW, int C, const void* x, const float
 //             dx = t*(dxhat - S1_b/n) - xhat*S2_b/((n-1)*std);  dgamma_c += sum_b s2;  dbeta_c += sum_b s1
 //   both written as dx = A[b][c]*g + Bc[b][c]*xhat + Cc[b][c]
 // ------------------------------------------------------------------------------------------
-template <int SM>
+template <int SX, int SG>      // storage of x and y | of dy (SX == ST_MIXED: run-time codes)
 __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __restrict__ x, const void* __restrict__ y,
                                                               const void* __restrict__ dy, NormST st, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int per_channel_stats,
@@ -436,25 +448,25 @@ __global__ void __launch_bounds__(256) norm_bwd_reduce_kernel(const void* __rest
         s2.z += g2 * (xv.z - mu.z) * rs.z; s2.w += g3 * (xv.w - mu.w) * rs.w;
     };
     const st_f32x4 ones = {1.f, 1.f, 1.f, 1.f};
-    auto ld = [&](const void* q, int64_t i, int code) __attribute__((always_inline)) { return st_ld4(q, i, SM == ST_MIXED ? code : SM); };
+    constexpr bool RT = SX == ST_MIXED;
+    const int cx = RT ? st.x : SX, cg_ = RT ? st.dy : SG, cy = RT ? st.y : SX;
     int p = p0 + pl;
-    for (; SM != ST_MIXED && p + (NU - 1) * PL < p1; p += NU * PL) {      // NU pixels' loads in flight, summed in the order of the plain loop (same bits)
+    for (; p + (NU - 1) * PL < p1; p += NU * PL) {      // NU pixels' loads in flight, summed in the order of the plain loop (same bits)
         st_f32x4 xv[NU], gv[NU], yv[NU];
+        const int64_t i0 = base + (int64_t)p * C4 + cg, istep = (int64_t)PL * C4;
+        st_ld4n<NU>(x, i0, istep, cx, xv);
+        st_ld4n<NU>(dy, i0, istep, cg_, gv);
+        if (need_y) st_ld4n<NU>(y, i0, istep, cy, yv);
+        else {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int64_t i = base + (int64_t)(p + u * PL) * C4 + cg;
-            xv[u] = ld(x, i, st.x); gv[u] = ld(dy, i, st.dy); yv[u] = ones;
-        }
-        if (need_y) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u) yv[u] = ld(y, base + (int64_t)(p + u * PL) * C4 + cg, st.y);
+            for (int u = 0; u < NU; ++u) yv[u] = ones;
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) acc(xv[u], gv[u], yv[u]);
     }
     for (; p < p1; p += PL) {
         const int64_t i = base + (int64_t)p * C4 + cg;
-        acc(ld(x, i, st.x), ld(dy, i, st.dy), need_y ? ld(y, i, st.y) : ones);
+        acc(st_ld4(x, i, cx), st_ld4(dy, i, cg_), need_y ? st_ld4(y, i, cy) : ones);
     }
     __shared__ float4 r1[256], r2[256];
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
@@ -568,8 +580,8 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_ln_kernel(const float2*
 
 // dx = A g + Bc xhat + Cc, g = dy act'(y) (+ the residual branch's gradient: dres (+)= g).  Same (gx, B) grid as norm_apply_kernel: the thread's
 // channel quad is fixed, its coefficients (mean, rstd, A, Bc, Cc, the forward's scale / shift) are loaded once, NU float4 per operand in flight
-// (SM as in norm_apply_kernel).
-template <int SM>
+// (SX: storage of x, y, dx and the residual branch's gradient | SG: of dy; SX == ST_MIXED: run-time codes).
+template <int SX, int SG>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ y,
                                                              const void* __restrict__ dy, NormST st, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int per_channel_stats,
@@ -594,8 +606,8 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restr
     if (from_x) { ksc = *reinterpret_cast<const float4*>(msc + o); ksh = *reinterpret_cast<const float4*>(msh + o); }
     const int64_t base = (int64_t)b * per4;
     const int stride = gridDim.x * 256;
-    auto ld = [&](const void* p, int64_t i, int code) __attribute__((always_inline)) { return st_ld4(p, i, SM == ST_MIXED ? code : SM); };
-    auto put = [&](void* p, int64_t i, st_f32x4 v, int code) __attribute__((always_inline)) { st_st4(p, i, v, SM == ST_MIXED ? code : SM); };
+    constexpr bool RT = SX == ST_MIXED;
+    const int cx = RT ? st.x : SX, cg_ = RT ? st.dy : SG, cy = RT ? st.y : SX, cdx = RT ? st.dx : SX, cdr = RT ? st.dres : SX;
     // g and dx of one float4 (yv: the activation's output, or -- from_x -- recomputed as the forward's own fmaf)
     auto one = [&](st_f32x4 xv, st_f32x4 gv, st_f32x4 yv, st_f32x4& g) __attribute__((always_inline)) {
         if (from_x) { yv.x = fmaf(xv.x, ksc.x, ksh.x); yv.y = fmaf(xv.y, ksc.y, ksh.y); yv.z = fmaf(xv.z, ksc.z, ksh.z); yv.w = fmaf(xv.w, ksc.w, ksh.w); }
@@ -610,38 +622,36 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const void* __restr
     };
     const st_f32x4 ones = {1.f, 1.f, 1.f, 1.f};
     int i = blockIdx.x * 256 + threadIdx.x;
-    for (; SM != ST_MIXED && i + (NU - 1) * stride < per4; i += NU * stride) {
+    for (; i + (NU - 1) * stride < per4; i += NU * stride) {
         st_f32x4 xv[NU], gv[NU], yv[NU], rv[NU];
+        st_ld4n<NU>(x, base + i, stride, cx, xv);
+        st_ld4n<NU>(dy, base + i, stride, cg_, gv);
+        if (need_y && !from_x) st_ld4n<NU>(y, base + i, stride, cy, yv);
+        else {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) { xv[u] = ld(x, base + i + u * stride, st.x); gv[u] = ld(dy, base + i + u * stride, st.dy); yv[u] = ones; }
-        if (need_y && !from_x) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u) yv[u] = ld(y, base + i + u * stride, st.y);
+            for (int u = 0; u < NU; ++u) yv[u] = ones;
         }
-        if (dres && dres_acc) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u) rv[u] = ld(dres, base + i + u * stride, st.dres);
-        }
+        if (dres && dres_acc) st_ld4n<NU>(dres, base + i, stride, cdr, rv);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             st_f32x4 g;
             const st_f32x4 d = one(xv[u], gv[u], yv[u], g);
-            put(dx, base + i + u * stride, d, st.dx);
+            st_st4(dx, base + i + u * stride, d, cdx);
             if (dres) {
                 if (dres_acc) g += rv[u];
-                put(dres, base + i + u * stride, g, st.dres);
+                st_st4(dres, base + i + u * stride, g, cdr);
             }
         }
     }
     for (; i < per4; i += stride) {
-        const st_f32x4 xv = ld(x, base + i, st.x), gv = ld(dy, base + i, st.dy);
-        const st_f32x4 yv = (need_y && !from_x) ? ld(y, base + i, st.y) : ones;
+        const st_f32x4 xv = st_ld4(x, base + i, cx), gv = st_ld4(dy, base + i, cg_);
+        const st_f32x4 yv = (need_y && !from_x) ? st_ld4(y, base + i, cy) : ones;
         st_f32x4 g;
         const st_f32x4 d = one(xv, gv, yv, g);
-        put(dx, base + i, d, st.dx);
+        st_st4(dx, base + i, d, cdx);
         if (dres) {
-            if (dres_acc) g += ld(dres, base + i, st.dres);
-            put(dres, base + i, g, st.dres);
+            if (dres_acc) g += st_ld4(dres, base + i, cdr);
+            st_st4(dres, base + i, g, cdr);
         }
     }
 }
@@ -662,13 +672,10 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
     const int pcs = kind != ACLGAN_NORM_LN;
     {
         const bool ry = act != ACLGAN_ACT_NONE && !msc;
-        const int sm = (sd.dy == sd.x && (!ry || sd.y == sd.x)) ? sd.x : ST_MIXED;
-#define ACL_NBR(SM) hipLaunchKernelGGL(norm_bwd_reduce_kernel<SM>, dim3(nchunks, B), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, part, HW, C, chunk, \
-                                       nchunks, act, msc, msh)
-        if (sm == ST_F32) ACL_NBR(ST_F32);
-        else if (sm == ST_BF16) ACL_NBR(ST_BF16);
-        else if (sm == ST_F16) ACL_NBR(ST_F16);
-        else ACL_NBR(ST_MIXED);
+        const int pair = (!ry || sd.y == sd.x) ? st_pair(sd.x, sd.dy) : -1;
+#define ACL_NBR(SX, SG) hipLaunchKernelGGL((norm_bwd_reduce_kernel<SX, SG>), dim3(nchunks, B), dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, part, HW, C, chunk, \
+                                           nchunks, act, msc, msh)
+        ACL_ST_PAIR_DISPATCH(pair, ACL_NBR);
 #undef ACL_NBR
     }
     ACL_CHECK_LAUNCH("norm_bwd_reduce_kernel");
@@ -691,13 +698,10 @@ int norm_bwd(int kind, int act, int B, int HW, int C, const void* x, const void*
     const int per4 = HW * (C / 4);
     const dim3 grid(rows_grid(per4, B), B);
     const bool need_y = act != ACLGAN_ACT_NONE && !msc;
-    const int sm = (sd.dy == sd.x && sd.dx == sd.x && (!need_y || sd.y == sd.x) && (!dres || sd.dres == sd.x)) ? sd.x : ST_MIXED;
-#define ACL_NBA(SM) hipLaunchKernelGGL(norm_bwd_apply_kernel<SM>, grid, dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, cA, cB, cC, dx, dres, \
-                                       dres_accumulate, per4, C, act, msc, msh)
-    if (sm == ST_F32) ACL_NBA(ST_F32);
-    else if (sm == ST_BF16) ACL_NBA(ST_BF16);
-    else if (sm == ST_F16) ACL_NBA(ST_F16);
-    else ACL_NBA(ST_MIXED);
+    const int pair = (sd.dx == sd.x && (!need_y || sd.y == sd.x) && (!dres || sd.dres == sd.x)) ? st_pair(sd.x, sd.dy) : -1;
+#define ACL_NBA(SX, SG) hipLaunchKernelGGL((norm_bwd_apply_kernel<SX, SG>), grid, dim3(256), 0, st, x, y, dy, sd, mean, rstd, pcs, cA, cB, cC, dx, dres, \
+                                           dres_accumulate, per4, C, act, msc, msh)
+    ACL_ST_PAIR_DISPATCH(pair, ACL_NBA);
 #undef ACL_NBA
     ACL_CHECK_LAUNCH("norm_bwd_apply_kernel");
     return ACLGAN_OK;

@@ -39,6 +39,30 @@ __device__ __forceinline__ st_f32x4 st_ld4(const void* __restrict__ p, int64_t i
     }
     return __builtin_convertvector(__builtin_bit_cast(st_f16x4, r), st_f32x4);
 }
+// N groups of 4 elements at group indices i0, i0 + step, ...: the storage branch is taken ONCE around the N loads.  (Inside an unrolled loop the
+// branch sits around every load and the compiler waits for a load at the end of its branch: one load in flight, whatever the unroll -- measured
+// in round 6 on the normalisation kernels; with a compile-time code the branch folds away and both forms are the same.)
+template <int N>
+__device__ __forceinline__ void st_ld4n(const void* __restrict__ p, int64_t i0, int64_t step, int st, st_f32x4 (&o)[N]) {
+    if (st == ST_F32) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) o[u] = reinterpret_cast<const st_f32x4*>(p)[i0 + u * step];
+        return;
+    }
+    st_u32x2 r[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) r[u] = reinterpret_cast<const st_u32x2*>(p)[i0 + u * step];
+    if (st == ST_BF16) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            o[u][0] = __builtin_bit_cast(float, r[u][0] << 16); o[u][1] = __builtin_bit_cast(float, r[u][0] & 0xffff0000u);
+            o[u][2] = __builtin_bit_cast(float, r[u][1] << 16); o[u][3] = __builtin_bit_cast(float, r[u][1] & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < N; ++u) o[u] = __builtin_convertvector(__builtin_bit_cast(st_f16x4, r[u]), st_f32x4);
+    }
+}
 __device__ __forceinline__ void st_st4(void* __restrict__ p, int64_t i4, st_f32x4 v, int st) {
     if (st == ST_F32) { reinterpret_cast<st_f32x4*>(p)[i4] = v; return; }
     if (st == ST_BF16) reinterpret_cast<st_u32x2*>(p)[i4] = __builtin_bit_cast(st_u32x2, __builtin_convertvector(v, st_bf16x4));
