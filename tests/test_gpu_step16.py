@@ -328,7 +328,7 @@ TRACK_BAND = {"bf16": {"loss_gen_total": 3.5e-1, "loss_dis_total": 3.5e-1}, "fp1
 TRACK_EARLY = {"bf16": 2e-2, "fp16": 5e-3}          # first five iterations: the precision of the dtype (measured 2.8e-3 / 9.0e-4)
 
 
-def test_loss_trajectory_16bit_tracks_fp32(T):
+def test_loss_trajectory_16bit_first_five_iterations_at_dtype_precision_and_no_blow_up_over_twenty(T):
     """Twenty chained iterations (dis_update, gen_update, update_learning_rate; reduced width, fixed batches and noise, lr x 10 so that the
     parameters move): the bf16 and fp16 HIP trainers follow the fp32 HIP trainer -- loss_gen_total and loss_dis_total of every iteration
     within a stated band over the whole run and at precision level over the first five iterations (only fp32 had chained-step and loop tests before).  fp16 runs under its
